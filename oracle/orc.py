@@ -1,0 +1,163 @@
+"""ctypes/numpy front-end of the C oracle (oracle/libray_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by ray_amd/.  Arrays are numpy float64, Fortran (column-major) order,
+laid out exactly like the reference's m / s / c / eval / grad (see ray_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import math
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libray_oracle.so")
+
+ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED = 1, 2, 4, 8, 16
+
+
+class SinProd(C.Structure):
+    _fields_ = [("A", C.c_double), ("wx", C.c_double), ("wy", C.c_double),
+                ("gx", C.c_double), ("gy", C.c_double)]
+
+
+class Obstacle(C.Structure):
+    _fields_ = [("kind", C.c_int), ("r0", C.c_double)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("kind", C.c_int), ("sp", SinProd), ("N", C.c_int), ("ext", C.c_double),
+                ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_shoot.restype = None
+        _lib.orc_trace_fixed_time.restype = None
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def linspace(a, b, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_linspace(C.c_double(a), C.c_double(b), C.c_int(n), _dp(out))
+    return out
+
+
+SMOOTH_DEMO = (0.3, 1.5 * np.pi, 1.5 * np.pi, 0.45 * np.pi, 0.45 * np.pi)   # NonObstacleDemo.jl:12,23
+OBSTACLE_DEMO = (0.2, 2 * np.pi, np.pi, 2 * (0.2 * np.pi), 0.2 * np.pi)      # ObstacleDemo.jl:12,18
+
+
+def sinprod_grid(params, N, ext):
+    """c[i,j] = waveSpeed(p[i], p[j]) (NonObstacle.jl:306), Fortran order (N,N)."""
+    A, wx, wy, _, _ = params
+    p = linspace(-ext, ext, N)
+    sx = np.array([math.sin(wx * float(v)) for v in p])
+    sy = np.array([math.sin(wy * float(v)) for v in p])
+    # 1 + A*sin(wx x)*sin(wy y): (A*sx)*sy then 1 + .
+    c = 1 + (A * sx)[:, None] * sy[None, :]
+    return np.asfortranarray(c)
+
+
+class GridTables:
+    def __init__(self, c, ext):
+        c = np.asfortranarray(c, dtype=np.float64)
+        N = c.shape[0]
+        assert c.shape == (N, N)
+        self.N, self.ext, self.c = N, float(ext), c
+        self.p = linspace(-ext, ext, N)
+        self.eval = np.zeros((N - 1, N - 1, 4), dtype=np.float64, order="F")
+        self.grad = np.zeros((N - 2, N - 2, 8), dtype=np.float64, order="F")
+        lib().orc_build_tables(_dp(c), C.c_int(N), C.c_double(ext), _dp(self.eval), _dp(self.grad))
+
+    def medium(self):
+        m = Medium()
+        m.kind = 1
+        m.N, m.ext = self.N, self.ext
+        m.eval, m.grad, m.p = _dp(self.eval), _dp(self.grad), _dp(self.p)
+        return m
+
+
+def analytic_medium(params):
+    m = Medium()
+    m.kind = 0
+    m.sp = SinProd(*params)
+    return m
+
+
+def _medium(med):
+    if isinstance(med, GridTables):
+        return med.medium()
+    if isinstance(med, Medium):
+        return med
+    return analytic_medium(med)
+
+
+def init_states(med, ns, nd, dir_lo=0.0, dir_hi=np.pi, src_begin=0, src_end=None):
+    src_end = ns if src_end is None else src_end
+    num = (src_end - src_begin) * nd
+    m = np.zeros((num, 9), dtype=np.float64, order="F")
+    mm = _medium(med)
+    lib().orc_init_states(C.byref(mm), C.c_int(ns), C.c_int(nd), C.c_double(dir_lo),
+                          C.c_double(dir_hi), C.c_int(src_begin), C.c_int(src_end), _dp(m),
+                          C.c_int64(num))
+    return m
+
+
+def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=1):
+    """In-place on m (Fortran (num,9)); returns (status, nsteps, nreflect)."""
+    assert m.flags.f_contiguous and m.dtype == np.float64 and m.shape[1] == 9
+    num = m.shape[0]
+    st = np.zeros(num, dtype=np.int32)
+    ns_ = np.zeros(num, dtype=np.int32)
+    nr = np.zeros(num, dtype=np.int32)
+    mm = _medium(med)
+    ob = Obstacle(0 if obstacle_r0 is None else 1, 0.0 if obstacle_r0 is None else obstacle_r0)
+    lib().orc_shoot(C.byref(mm), C.byref(ob), C.c_double(dt), C.c_int(time_unit),
+                    C.c_int(max_steps), _dp(m), C.c_int64(num), C.c_int64(num), _dp(st), _dp(ns_),
+                    _dp(nr), C.c_int(nthreads))
+    return st, ns_, nr
+
+
+def scatter_relation(med, ns, nd, dt, dir_lo=0.0, dir_hi=np.pi, obstacle_r0=None, time_unit=0,
+                     src_begin=0, src_end=None, max_steps=100000, nthreads=1):
+    m = init_states(med, ns, nd, dir_lo, dir_hi, src_begin, src_end)
+    st, nsteps, nref = shoot(med, m, dt, obstacle_r0, time_unit, max_steps, nthreads)
+    return m, st, nsteps, nref
+
+
+def trace_fixed_time(tab, m_in, dt, mode, nthreads=1):
+    assert m_in.flags.f_contiguous and m_in.shape[1] == 9
+    num = m_in.shape[0]
+    X = np.zeros((num, 4), dtype=np.float64, order="F")
+    st = np.zeros(num, dtype=np.int32)
+    ns_ = np.zeros(num, dtype=np.int32)
+    lib().orc_trace_fixed_time(_dp(tab.eval), _dp(tab.grad), _dp(tab.p), C.c_int(tab.N),
+                               C.c_double(dt), C.c_int(mode), _dp(m_in), C.c_int64(num),
+                               C.c_int64(num), _dp(X), C.c_int64(num), _dp(st), _dp(ns_),
+                               C.c_int(nthreads))
+    return X, st, ns_
+
+
+def misfit(m, obs, thresh=0.2):
+    num = m.shape[0]
+    mism = np.zeros(4 * num, dtype=np.float64)
+    out = np.zeros(2, dtype=np.float64)
+    mask = np.zeros(num, dtype=np.uint8)
+    lib().orc_misfit(_dp(m), _dp(obs), C.c_int64(num), C.c_int64(num), _dp(mism), _dp(out),
+                     _dp(mask), C.c_double(thresh))
+    return mism, out, mask

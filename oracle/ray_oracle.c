@@ -1,0 +1,412 @@
+/*
+ * ray_oracle.c -- scalar fp64 CPU restatement of lowrank/ray's forward ray-shooting path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ray_oracle.h).  "parity unpinned" by the reference: it has no
+ * tests/golden vectors and cannot be executed here; see the header for how this file is pinned.
+ *
+ * Build:  gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC  (oracle/Makefile)
+ * Every floating-point expression below is written in the reference's evaluation order;
+ * -ffp-contract=off forbids the compiler from fusing a*b+c, so each operator is one IEEE
+ * binary64 rounding exactly as in un-fused Julia code.  fma() appears only inside the
+ * double-double helper used for linspace (Julia's TwicePrecision range indexing).
+ *
+ * Assumed Julia-0.6 semantics (not verifiable offline):
+ *   norm(v) for short vectors = sqrt(v1^2 + v2^2 ...) left to right (generic_vecnorm2, no rescale)
+ *   a'*b                      = left-to-right dot product
+ *   linspace(a,b,n)[k]        = correctly rounded a + (k-1)(b-a)/(n-1)   (TwicePrecision)
+ *   n-ary a+b+c, a*b*c        = left to right
+ */
+#include "ray_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * double-double helpers (only for linspace)
+ * ---------------------------------------------------------------------------------------- */
+static void two_sum(double a, double b, double *s, double *e)
+{
+    double ss = a + b;
+    double bb = ss - a;
+    *e = (a - (ss - bb)) + (b - bb);
+    *s = ss;
+}
+static void two_prod(double a, double b, double *p, double *e)
+{
+    double pp = a * b;
+    *e = fma(a, b, -pp);
+    *p = pp;
+}
+
+/* NonObstacle.jl:55-56,191 / Obstacle.jl:12-13 : linspace(a,b,n); out[k-1] = p[k].
+ * Julia 0.6 StepRangeLen{Float64,TwicePrecision}: ref + (k-1)*step evaluated in ~106 bits and
+ * rounded once.  Restated as double-double arithmetic on the exact doubles a, b.             */
+void orc_linspace(double a, double b, int n, double *out)
+{
+    if (n == 1) { out[0] = a; return; }
+    double dh, dl;                      /* d = b - a, exact as a double-double */
+    two_sum(b, -a, &dh, &dl);
+    double m = (double)(n - 1);
+    /* q = d / m in double-double */
+    double qh = dh / m, ph, pl;
+    two_prod(qh, m, &ph, &pl);
+    double r = ((dh - ph) - pl) + dl;
+    double ql = r / m;
+    double t;
+    two_sum(qh, ql, &qh, &t); ql = t;
+    for (int k = 1; k <= n; ++k) {
+        double u = (double)(k - 1);
+        double th, tl;
+        two_prod(qh, u, &th, &tl);
+        tl += ql * u;
+        double sh, sl;
+        two_sum(a, th, &sh, &sl);
+        sl += tl;
+        out[k - 1] = sh + sl;
+    }
+    out[n - 1] = b;                     /* Julia ranges hit the endpoint exactly */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * a4: Q4  (NonObstacle.jl:103-105).  I,J are 1-based as in the reference.
+ * ---------------------------------------------------------------------------------------- */
+#define C_(I, J) c[((I) - 1) + (int64_t)((J) - 1) * N]
+void orc_q4(const double *c, int N, int I, int J, double dx, double q[4])
+{
+    q[0] = C_(I, J);
+    q[1] = (C_(I + 1, J) - C_(I, J)) / dx;
+    q[2] = (C_(I, J + 1) - C_(I, J)) / dx;
+    q[3] = (((C_(I + 1, J + 1) + C_(I, J)) - C_(I + 1, J)) - C_(I, J + 1)) / (dx * dx);
+}
+
+/* a5: table build (NonObstacle.jl:191-210; duplicated Obstacle.jl:224-241, 277-294).
+ * eval (N-1,N-1,4), grad (N-2,N-2,8), column-major; grad entries with I==1 or J==1 are never
+ * written by the reference (SharedArray is zero-filled) -> zero here.                        */
+void orc_build_tables(const double *c, int N, double ext, double *eval, double *grad)
+{
+    const int64_t n1 = N - 1, n2 = N - 2;
+    double dx = 2 * ext / (N - 1);
+    memset(grad, 0, sizeof(double) * (size_t)(n2 * n2 * 8));
+    for (int I = 1; I <= N - 1; ++I)
+        for (int J = 1; J <= N - 1; ++J) {
+            double q[4];
+            orc_q4(c, N, I, J, dx, q);
+            for (int k = 0; k < 4; ++k) eval[(I - 1) + (J - 1) * n1 + k * n1 * n1] = q[k];
+        }
+#define EV(I, J, k) eval[((I) - 1) + ((J) - 1) * n1 + (int64_t)(k) * n1 * n1]
+    for (int I = 2; I <= N - 2; ++I)
+        for (int J = 2; J <= N - 2; ++J)
+            for (int k = 0; k < 4; ++k) {
+                grad[(I - 1) + (J - 1) * n2 + (int64_t)k * n2 * n2] =
+                    (EV(I + 1, J, k) - EV(I - 1, J, k)) / (2 * dx);
+                grad[(I - 1) + (J - 1) * n2 + (int64_t)(k + 4) * n2 * n2] =
+                    (EV(I, J + 1, k) - EV(I, J - 1, k)) / (2 * dx);
+            }
+#undef EV
+}
+
+/* cell index: I = Int64(floor((x - p[1]) / h)) + 1  (NonObstacle.jl:33-34).
+ * The reference indexes out of bounds (UB under @inbounds) when I is outside [1, N-2];
+ * here the index is clamped and *oob set.                                                   */
+static int cell_index(double x, double p1, double h, int N, int *oob)
+{
+    double q = floor((x - p1) / h);
+    int I;
+    if (!(q >= 0.0)) { I = 1; *oob = 1; }                /* also catches NaN */
+    else if (q > (double)(N - 3)) { I = N - 2; *oob = 1; }
+    else I = (int)q + 1;
+    return I;
+}
+
+/* bilinear table value  z' * tab[I,J,k0:k0+3]  left to right (NonObstacle.jl:37-41) */
+static double zdot(double dx, double dy, double dxdy, const double *tab, int64_t base,
+                   int64_t plane, int k0)
+{
+    double s = 1.0 * tab[base + (k0 + 0) * plane];
+    s = s + dx * tab[base + (k0 + 1) * plane];
+    s = s + dy * tab[base + (k0 + 2) * plane];
+    s = s + dxdy * tab[base + (k0 + 3) * plane];
+    return s;
+}
+
+/* a2: DiscreteHamilton without Hessian (NonObstacle.jl:30-52); a3's H output is identical
+ * (NonObstacle.jl:6-18).  Returns 1 if an index had to be clamped.                          */
+int orc_discrete_hamilton(const double X[4], const double *eval, const double *grad,
+                          const double *p, int N, double H[4])
+{
+    int oob = 0;
+    const int64_t n1 = N - 1, n2 = N - 2;
+    double h = p[1] - p[0];
+    int I = cell_index(X[0], p[0], h, N, &oob);
+    int J = cell_index(X[1], p[0], h, N, &oob);
+    double dx = X[0] - p[I - 1], dy = X[1] - p[J - 1];
+    double dxdy = dx * dy;
+    double tau = X[2] * X[2] + X[3] * X[3];
+    double c = zdot(dx, dy, dxdy, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
+    double gcX = zdot(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 0);
+    double gcY = zdot(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 4);
+    double c2 = c * c;
+    H[0] = c2 * X[2];
+    H[1] = c2 * X[3];
+    H[2] = ((-gcX) * c) * tau;
+    H[3] = ((-gcY) * c) * tau;
+    return oob;
+}
+
+/* gridded c(x,y) alone: z' * eval[I,J,:] (used for c(sensor) when shooting on a grid) */
+static double grid_speed(double x, double y, const double *eval, const double *p, int N, int *oob)
+{
+    const int64_t n1 = N - 1;
+    double h = p[1] - p[0];
+    int I = cell_index(x, p[0], h, N, oob);
+    int J = cell_index(y, p[0], h, N, oob);
+    double dx = x - p[I - 1], dy = y - p[J - 1];
+    return zdot(dx, dy, dx * dy, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
+}
+
+/* a12 media (NonObstacleDemo.jl:12,23; ObstacleDemo.jl:12,18) */
+static double sinprod_c(const orc_sinprod *sp, double x, double y)
+{
+    return 1 + sp->A * sin(sp->wx * x) * sin(sp->wy * y);
+}
+
+/* a1: Hamilton (NonObstacle.jl:1-4):  [speed^2 * p ; -(p'p) * gradc * speed] */
+void orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4])
+{
+    double sx = sin(sp->wx * X[0]), cx = cos(sp->wx * X[0]);
+    double sy = sin(sp->wy * X[1]), cy = cos(sp->wy * X[1]);
+    double speed = 1 + sp->A * sx * sy;
+    double g0 = sp->gx * (cx * sy);
+    double g1 = sp->gy * (sx * cy);
+    double tau = X[2] * X[2] + X[3] * X[3];
+    double s2 = speed * speed;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = ((-tau) * g0) * speed;
+    H[3] = ((-tau) * g1) * speed;
+}
+
+static int rhs(const orc_medium *med, const double X[4], double H[4])
+{
+    if (med->kind == 0) { orc_hamilton_sinprod(X, &med->sp, H); return 0; }
+    return orc_discrete_hamilton(X, med->eval, med->grad, med->p, med->N, H);
+}
+
+/* a6 init (NonObstacle.jl:55-65; Obstacle.jl:12-22) */
+void orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, double dir_hi,
+                     int src_begin, int src_end, double *m, int64_t ld)
+{
+    double *source = (double *)malloc(sizeof(double) * (size_t)(ns + 1));
+    double *direct = (double *)malloc(sizeof(double) * (size_t)(nd + 2));
+    orc_linspace(0.0, 2 * M_PI, ns + 1, source);
+    orc_linspace(dir_lo, dir_hi, nd + 2, direct);
+    for (int i = src_begin; i < src_end; ++i) {
+        double sx = cos(source[i]), sy = sin(source[i]);
+        int oob = 0;
+        double cs = med->kind == 0 ? sinprod_c(&med->sp, sx, sy)
+                                   : grid_speed(sx, sy, med->eval, med->p, med->N, &oob);
+        for (int j = 0; j < nd; ++j) {
+            double theta = source[i] + M_PI * 0.5 + direct[j + 1];
+            int64_t r = (int64_t)(i - src_begin) * nd + j;
+            m[r + 0 * ld] = sx;
+            m[r + 1 * ld] = sy;
+            m[r + 2 * ld] = cos(theta) / cs;
+            m[r + 3 * ld] = sin(theta) / cs;
+        }
+    }
+    free(source);
+    free(direct);
+}
+
+static double norm2(double a, double b) { return sqrt(a * a + b * b); }
+
+/* obstacle level set and normal (ObstacleDemo.jl:20-34, circle branch) */
+static double ob_val(const orc_obstacle *ob, double x, double y)
+{
+    return norm2(x, y) - ob->r0;
+}
+static void ob_normal(const orc_obstacle *ob, double x, double y, double n[2])
+{
+    (void)ob;
+    double r = norm2(x, y);
+    double nx = x / r, ny = y / r;
+    double nn = norm2(nx, ny);
+    n[0] = nx / nn;
+    n[1] = ny / nn;
+}
+
+/* one classical RK4 step in the a6/a7 form: k = H*dt, X + k1/2, ... /6.0
+ * (NonObstacle.jl:72-76; Obstacle.jl:34-38) */
+static int rk4_step_kdt(const orc_medium *med, double X[4], double dt)
+{
+    double k1[4], k2[4], k3[4], k4[4], Y[4], H[4];
+    int oob = 0;
+    oob |= rhs(med, X, H);
+    for (int k = 0; k < 4; ++k) { k1[k] = H[k] * dt; Y[k] = X[k] + k1[k] / 2; }
+    oob |= rhs(med, Y, H);
+    for (int k = 0; k < 4; ++k) { k2[k] = H[k] * dt; Y[k] = X[k] + k2[k] / 2; }
+    oob |= rhs(med, Y, H);
+    for (int k = 0; k < 4; ++k) { k3[k] = H[k] * dt; Y[k] = X[k] + k3[k]; }
+    oob |= rhs(med, Y, H);
+    for (int k = 0; k < 4; ++k) {
+        k4[k] = H[k] * dt;
+        X[k] = X[k] + (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]) / 6.0;
+    }
+    return oob;
+}
+
+static void shoot_one(const orc_medium *med, const orc_obstacle *ob, double dt, int time_unit,
+                      int max_steps, double *m, int64_t r, int64_t ld, int32_t *status,
+                      int32_t *nsteps, int32_t *nreflect)
+{
+    double X[4], prev[4], E[4];
+    for (int k = 0; k < 4; ++k) X[k] = m[r + k * ld];
+    double t = 0;
+    int rfl = 0, st = 0, steps = 0, nref = 0;
+    const int has_ob = ob && ob->kind != 0;
+    for (;;) {
+        if (steps >= max_steps) { st |= ORC_ST_STEP_CAP; break; }
+        if (has_ob && ob_val(ob, X[0], X[1]) > 0) rfl = 0;          /* Obstacle.jl:28-30 */
+        for (int k = 0; k < 4; ++k) prev[k] = X[k];
+        if (rk4_step_kdt(med, X, dt)) st |= ORC_ST_OOB;
+        ++steps;
+        t = time_unit ? t + 1 : t + dt;            /* Obstacle.jl:39 / NonObstacle.jl:77 */
+        if (norm2(X[0], X[1]) >= 1) {              /* NonObstacle.jl:78-93; Obstacle.jl:40-57 */
+            double lo = 0, hi = 1, mid, e;
+            int it = 0;
+            mid = (lo + hi) / 2;
+            for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * prev[k] + mid * X[k];
+            e = norm2(E[0], E[1]) - 1;
+            while (fabs(e) > 1e-15) {
+                if (++it > ORC_BISECT_CAP) { st |= ORC_ST_BISECT_CAP; break; }
+                if (e > 0) hi = mid; else lo = mid;
+                mid = (lo + hi) / 2;
+                for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * prev[k] + mid * X[k];
+                e = norm2(E[0], E[1]) - 1;
+            }
+            t = time_unit ? t - (1 - mid) : t - (1 - mid) * dt;
+            for (int k = 0; k < 4; ++k) X[k] = E[k];
+            st |= ORC_ST_EXITED;
+            break;
+        }
+        if (has_ob && ob_val(ob, X[0], X[1]) <= 0 && rfl == 0) {    /* Obstacle.jl:69-91 */
+            double lo = 0, hi = 1, mid, e, n[2];
+            int it = 0;
+            rfl = 1;
+            mid = (lo + hi) / 2;
+            for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * prev[k] + mid * X[k];
+            e = ob_val(ob, E[0], E[1]);
+            while (fabs(e) > 1e-15) {
+                if (++it > ORC_BISECT_CAP) { st |= ORC_ST_BISECT_CAP; break; }
+                if (e > 0) lo = mid; else hi = mid;
+                mid = (lo + hi) / 2;
+                for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * prev[k] + mid * X[k];
+                e = ob_val(ob, E[0], E[1]);
+            }
+            ob_normal(ob, E[0], E[1], n);                             /* Obstacle.jl:84 */
+            /* X[3:4] = (eye(2) - 2*n*n') * R[3:4]                       Obstacle.jl:85 */
+            double a0 = 2 * n[0], a1 = 2 * n[1];
+            double m11 = 1 - a0 * n[0], m12 = 0 - a0 * n[1];
+            double m21 = 0 - a1 * n[0], m22 = 1 - a1 * n[1];
+            X[0] = E[0];
+            X[1] = E[1];
+            X[2] = m11 * E[2] + m12 * E[3];
+            X[3] = m21 * E[2] + m22 * E[3];
+            ++nref;
+        }
+    }
+    for (int k = 0; k < 4; ++k) m[r + (4 + k) * ld] = X[k];
+    m[r + 8 * ld] = t;
+    if (status) status[r] = st;
+    if (nsteps) nsteps[r] = steps;
+    if (nreflect) nreflect[r] = nref;
+}
+
+void orc_shoot(const orc_medium *med, const orc_obstacle *ob, double dt, int time_unit,
+               int max_steps, double *m, int64_t num, int64_t ld, int32_t *status,
+               int32_t *nsteps, int32_t *nreflect, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t r = 0; r < num; ++r)
+        shoot_one(med, ob, dt, time_unit, max_steps, m, r, ld, status, nsteps, nreflect);
+}
+
+/* RK4 step in the a8/a9 form: k = H, X + k/2*dt, X += (k1+2k2+2k3+k4)*dt/6.0
+ * (NonObstacle.jl:161-164,171; Obstacle.jl:312-317) */
+static int rk4_step_k(const double *eval, const double *grad, const double *p, int N,
+                      double X[4], double dt)
+{
+    double k1[4], k2[4], k3[4], k4[4], Y[4];
+    int oob = 0;
+    oob |= orc_discrete_hamilton(X, eval, grad, p, N, k1);
+    for (int k = 0; k < 4; ++k) Y[k] = X[k] + k1[k] / 2 * dt;
+    oob |= orc_discrete_hamilton(Y, eval, grad, p, N, k2);
+    for (int k = 0; k < 4; ++k) Y[k] = X[k] + k2[k] / 2 * dt;
+    oob |= orc_discrete_hamilton(Y, eval, grad, p, N, k3);
+    for (int k = 0; k < 4; ++k) Y[k] = X[k] + k3[k] * dt;
+    oob |= orc_discrete_hamilton(Y, eval, grad, p, N, k4);
+    for (int k = 0; k < 4; ++k)
+        X[k] = X[k] + (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]) * dt / 6.0;
+    return oob;
+}
+
+#define ORC_FIXED_STEP_CAP 10000000
+
+void orc_trace_fixed_time(const double *eval, const double *grad, const double *p, int N,
+                          double timeStep, int mode, const double *m_in, int64_t num, int64_t ld,
+                          double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
+                          int nthreads)
+{
+    (void)nthreads;
+    const double cease_r = 1 + 2 * (p[1] - p[0]);                  /* NonObstacle.jl:177 */
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < num; ++i) {
+        double X[4];
+        for (int k = 0; k < 4; ++k) X[k] = m_in[i + k * ld];
+        const double Ti = m_in[i + 8 * ld];
+        double t = 0, dt = timeStep;
+        int st = 0, steps = 0;
+        while (t < Ti) {
+            if (steps >= ORC_FIXED_STEP_CAP) { st |= ORC_ST_STEP_CAP; break; }
+            if (mode == 0 && (t + dt) > Ti) dt = Ti - t;          /* NonObstacle.jl:153-156 */
+            t = t + dt;                                           /* :157 / Obstacle.jl:311 */
+            if (rk4_step_k(eval, grad, p, N, X, dt)) st |= ORC_ST_OOB;
+            ++steps;
+            if (mode == 0 && norm2(X[0], X[1]) > cease_r) {       /* NonObstacle.jl:177-181 */
+                t = t + (Ti - t);
+                st |= ORC_ST_CEASED;
+            }
+        }
+        for (int k = 0; k < 4; ++k) X_out[i + k * ldx] = X[k];
+        if (status) status[i] = st;
+        if (nsteps) nsteps[i] = steps;
+    }
+}
+
+/* a11: NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252 */
+void orc_misfit(const double *m, const double *obs, int64_t num, int64_t ld, double *mismatch,
+                double out[2], uint8_t *mask, double thresh)
+{
+    double sm = 0, st = 0;
+    for (int64_t r = 0; r < num; ++r) {
+        double d[4], a[4];
+        for (int k = 0; k < 4; ++k) {
+            a[k] = m[r + (4 + k) * ld];
+            d[k] = a[k] - obs[r + (4 + k) * ld];
+            if (mismatch) mismatch[4 * r + k] = d[k];
+            sm = sm + d[k] * d[k];
+            st = st + a[k] * a[k];
+        }
+        if (mask) {
+            double nd_ = sqrt(((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]);
+            double na = sqrt(((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]) + a[3] * a[3]);
+            mask[r] = (nd_ / na < thresh) ? 1 : 0;
+        }
+    }
+    out[0] = sm;
+    out[1] = st;
+}

@@ -1,0 +1,86 @@
+/*
+ * ray_oracle.h -- CPU restatement of the forward ray-shooting path of lowrank/ray.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (ray_amd/, include/) may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ *
+ * PARITY STATUS: "parity unpinned" by the reference.  The reference is Julia-0.6-only
+ * code with no tests, no golden vectors and no runnable interpreter in this image
+ * (SURVEY.md section 8c).  This restatement follows the reference's operation order line by
+ * line (citations at each function) and is pinned by (1) an independent pure-Python
+ * restatement (oracle/ray_oracle.py) that must agree bit for bit, (2) closed-form
+ * known-answer tests (tests/test_oracle_kat.py), (3) committed golden fixtures generated
+ * by the Python restatement (tests/golden/).
+ *
+ * Array conventions (same as the reference):
+ *   m, s     : double (num, 9) COLUMN-major with leading dimension ld  -> m[r + k*ld]
+ *              columns [x0 y0 px0 py0 x1 y1 px1 py1 t]
+ *   c        : double (N, N) column-major, first index = x           (NonObstacle.jl:102,306)
+ *   eval     : double (N-1, N-1, 4) column-major                      (NonObstacle.jl:192)
+ *   grad     : double (N-2, N-2, 8) column-major                      (NonObstacle.jl:193)
+ */
+#ifndef RAY_ORACLE_H
+#define RAY_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status bits (shared vocabulary with include/ray_amd.h; values restated, not included) */
+#define ORC_ST_EXITED      0x01  /* left the unit disk, exit refined by bisection            */
+#define ORC_ST_STEP_CAP    0x02  /* max_steps reached (reference would loop forever)          */
+#define ORC_ST_BISECT_CAP  0x04  /* a bisection hit its iteration cap                         */
+#define ORC_ST_OOB         0x08  /* a table lookup fell outside the valid cell range, clamped */
+#define ORC_ST_CEASED      0x10  /* a9 only: ray left 1+2h and was ceased                     */
+
+#define ORC_BISECT_CAP 200
+
+/* analytic medium family  c = 1 + A sin(wx x) sin(wy y),
+ * grad c = [gx cos(wx x) sin(wy y), gy sin(wx x) cos(wy y)]
+ * NonObstacleDemo.jl:12,23 -> A=0.3 wx=wy=1.5*pi gx=gy=0.45*pi
+ * ObstacleDemo.jl:12,18    -> A=0.2 wx=2*pi wy=pi gx=2*(0.2*pi) gy=0.2*pi            */
+typedef struct { double A, wx, wy, gx, gy; } orc_sinprod;
+
+/* obstacle family: kind 0 none, 1 circle r - r0 (ObstacleDemo.jl:20-34) */
+typedef struct { int kind; double r0; } orc_obstacle;
+
+typedef struct {
+    int kind;              /* 0 = sinprod analytic, 1 = grid tables */
+    orc_sinprod sp;
+    int N; double ext;     /* grid */
+    const double *eval, *grad, *p;
+} orc_medium;
+
+void   orc_linspace(double a, double b, int n, double *out);
+void   orc_q4(const double *c, int N, int I, int J, double dx, double q[4]);
+void   orc_build_tables(const double *c, int N, double ext, double *eval, double *grad);
+int    orc_discrete_hamilton(const double X[4], const double *eval, const double *grad,
+                             const double *p, int N, double H[4]);
+void   orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4]);
+
+/* initial boundary phase-space grid, rows for sources [src_begin, src_end) */
+void   orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, double dir_hi,
+                       int src_begin, int src_end, double *m, int64_t ld);
+
+/* a6 / a7: shoot rows [0,num) of m from m[:,1:4]; obstacle may be kind 0.
+ * time_unit: 0 = seconds (a6: t += dt), 1 = steps (a7: t += 1).                      */
+void   orc_shoot(const orc_medium *med, const orc_obstacle *ob, double dt, int time_unit,
+                 int max_steps, double *m, int64_t num, int64_t ld,
+                 int32_t *status, int32_t *nsteps, int32_t *nreflect, int nthreads);
+
+/* a8 (mode 1: overshoot) / a9 X-only (mode 0: shorten last step + cease) */
+void   orc_trace_fixed_time(const double *eval, const double *grad, const double *p, int N,
+                            double dt, int mode, const double *m_in, int64_t num, int64_t ld,
+                            double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
+                            int nthreads);
+
+/* a11 */
+void   orc_misfit(const double *m, const double *obs, int64_t num, int64_t ld,
+                  double *mismatch /* 4*num or NULL */, double out[2] /* sum mismatch^2, sum target^2 */,
+                  uint8_t *mask /* num or NULL */, double thresh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
