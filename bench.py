@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the forward ray-shooting core (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+  shoot-to-exit of a 2048 x 2048 (theta, phi) boundary phase-space grid per GPU on a 512^2 fp64
+  wavespeed grid (BASELINE.json configs[1]; init generated on device, outputs stay in HBM)
+  + the misfit reduction against an observation resident in HBM
+  + (N > 1) ONE all-reduce (RCCL) of {sum mismatch^2, sum target^2}.
+N > 1: rays shard by theta-block, rank r shoots sources [r*2048, (r+1)*2048) of a (2048*N) x 2048
+grid (weak scaling: per-GPU work fixed); no ray data is exchanged.
+
+Prints ONE JSON line (rank 0).  `value` = ray-steps/s of the whole job; `roofline` prices the
+shoot kernel at SURVEY.md section 8(d)'s 225 algorithmic flop per ray-step against the fp64 VECTOR peak
+(78.6 TFLOP/s; there is no dense contraction, so neither the HBM nor the MFMA roofline binds);
+`cpu_baseline` times the CPU oracle (a C port of the reference's Julia path: Julia is not
+installed and the reference is Julia-0.6-only) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_STEP_GRID = 225            # algorithmic fp64 flop per ray-step, SURVEY.md section 8(d)
+FP64_VECTOR_PEAK = 78.6      # TFLOP/s: 256 CU x 4 SIMD x 16 lanes x 2 (FMA) x 2.4 GHz
+NS_PER_GPU, ND, NGRID, EXT, DT = 2048, 2048, 512, 1.5, 1e-2
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle (oracle/ray_oracle.c, a C port of the reference's CPU path) on a bounded
+    sample of the same workload: the first S sources x all 2048 directions."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, NGRID, EXT)
+    tab = orc.GridTables(c, EXT)
+    t0 = time.perf_counter()
+    _, _, nst, _ = orc.scatter_relation(tab, NS_PER_GPU, ND, DT, src_begin=0, src_end=2, nthreads=threads)
+    rate = nst.sum() / (time.perf_counter() - t0)
+    S = int(max(2, min(NS_PER_GPU, rate * seconds_target / (127.0 * ND))))
+    t0 = time.perf_counter()
+    _, _, nst, _ = orc.scatter_relation(tab, NS_PER_GPU, ND, DT, src_begin=0, src_end=S, nthreads=threads)
+    el = time.perf_counter() - t0
+    return {"value": float(nst.sum() / el), "unit": "ray-steps/s", "cores": threads, "kind": "port",
+            "sample": f"sources [0,{S}) x {ND} directions of the same 2048x2048 / 512^2 / dt=1e-2 "
+                      f"workload: {int(nst.sum())} ray-steps in {el:.2f} s (C port of the "
+                      "reference's Julia CPU path, -O2 -ffp-contract=off, OpenMP over rays)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ray_amd
+    from ray_amd import device as rdev
+
+    ctx = ray_amd.Context(local)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # synthetic medium: c = 1 + 0.3 sin(1.5 pi x) sin(1.5 pi y) on linspace(-1.5,1.5,512)^2
+    sp = ray_amd.SinProd.smooth_demo()
+    p = np.zeros(NGRID)
+    ray_amd._lib.check(ctx._lib.ray_linspace(-EXT, EXT, NGRID, p.ctypes.data))
+    c = np.asfortranarray([[sp(float(x), float(y)) for y in p] for x in p])
+    med = ray_amd.GridMedium(c, EXT, ctx)
+
+    ns_total = NS_PER_GPU * world
+    sb, se = rank * NS_PER_GPU, (rank + 1) * NS_PER_GPU
+    num = NS_PER_GPU * ND
+    m = torch.empty(9 * num, dtype=torch.float64, device=dev)
+    obs = torch.zeros(9 * num, dtype=torch.float64, device=dev)
+    status = torch.empty(num, dtype=torch.int32, device=dev)
+    nsteps = torch.empty(num, dtype=torch.int32, device=dev)
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def step():
+        rdev.shoot_to_exit_dev(ctx, med, ns_total, ND, DT, m.data_ptr(), num, src_begin=sb, src_end=se,
+                               status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr())
+        rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, sums.data_ptr())
+        if world > 1:
+            dist.all_reduce(sums)          # the one collective per iteration (misfit sums)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # the observation = the data itself from a first pass, perturbed (misfit cost is data-independent)
+    step()
+    torch.cuda.synchronize()
+    obs.copy_(m)
+    obs[4 * num:8 * num] *= 1.001
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.reset_counters()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    cnt = ctx.counters()
+    ctx.enable_timing(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(cnt["ray_steps"]), float(cnt["rays"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot)
+    elapsed = float(el.item())
+    ray_steps, rays = float(tot[0].item()), float(tot[1].item())
+
+    bad = int((status != ray_amd.ST_EXITED).sum().item())
+    if bad:
+        raise SystemExit(f"{bad} rays did not exit cleanly")
+
+    if rank == 0:
+        kern_s = cnt["kernel_ms"] * 1e-3 / max(cnt["launches"], 1)
+        steps_per_launch = cnt["ray_steps"] / max(cnt["launches"], 1)
+        achieved = F_STEP_GRID * steps_per_launch / kern_s / 1e12
+        out = {
+            "metric": "fp64 RK4 ray-steps/sec", "value": ray_steps / elapsed, "unit": "ray-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rays_per_s": rays / elapsed,
+            "config": {"workload": "forward shooting to exit, 2048x2048 (theta,phi) rays per GPU, "
+                                   "512^2 fp64 wavespeed grid, dt=1e-2 (BASELINE configs[1]) + misfit "
+                                   "reduction" + (" + 1 all-reduce" if world > 1 else ""),
+                       "ns_total": ns_total, "nd": ND, "grid": NGRID, "dt": DT,
+                       "rays_per_gpu": num, "mean_steps_per_ray": steps_per_launch / num,
+                       "parallelism": f"theta-block x{world}"},
+            "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",
+                         "achieved": achieved, "peak": FP64_VECTOR_PEAK, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK, "traffic": None,
+                         "kernel_ms": kern_s * 1e3, "ray_steps_per_launch": steps_per_launch,
+                         "flop_per_ray_step": F_STEP_GRID,
+                         "kernel_ray_steps_per_s": steps_per_launch / kern_s},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * ray_amd.h -- C ABI of libray_amd.so: the MI355X (gfx950) forward ray-shooting core that
+ * replaces the per-ray loops of lowrank/ray (reference citations are file:line under the
+ * reference tree; SURVEY.md section 8 is the scope table).
+ *
+ * The reference has no FFI: its boundary is the set of Julia call sites
+ *   ScatterRelation            NonObstacle.jl:54    (called NonObstacleDemo.jl:32)
+ *   ScatterRelationObstacle    Obstacle.jl:11       (called ObstacleDemo.jl:43,306)
+ *   ScatterForwardOperator     NonObstacle.jl:189   (called NonObstacle.jl:333, ObstacleDemo.jl:199)
+ *   NonReflectionTrace         Obstacle.jl:275
+ *   misfit / objective / perc  NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252
+ * A Julia shim (julia/RayAMD.jl) and a Python mirror (ray_amd/) keep those names and ccall /
+ * ctypes into the entry points below.  INTEGRATION.md shows the bindings.
+ *
+ * Conventions
+ *   - every function returns int: 0 = RAY_OK, negative = error class; ray_last_error() gives
+ *     a thread-local message.  No exceptions cross the ABI, no callbacks into the caller.
+ *   - arrays are caller-owned, fp64, COLUMN-major exactly as the reference lays them out:
+ *       m, s : (num, 9) with leading dimension ld -> element (r,k) at m[r + k*ld],
+ *              columns [x0 y0 px0 py0 x1 y1 px1 py1 t]      (NonObstacle.jl:58,63,95-96)
+ *       c    : (N, N), first index = x                        (NonObstacle.jl:102,306)
+ *   - plain entry points take HOST pointers and are synchronous (results valid on return,
+ *     which is what a blocking Julia ccall needs).  *_dev entry points take DEVICE pointers,
+ *     enqueue on the context's stream and return immediately; ray_ctx_synchronize() waits.
+ *   - one ray_ctx per GPU; a ctx and its media must be used from one thread at a time.
+ *   - function-valued arguments of the reference (c, grad c, ob, grad ob closures) cannot
+ *     cross a C ABI onto a GPU: media and obstacles are closed parametric families that cover
+ *     what the reference's demos ship, plus the gridded medium.
+ */
+#ifndef RAY_AMD_H
+#define RAY_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAY_OK               0
+#define RAY_ERR_INVALID     -1   /* bad argument / shape */
+#define RAY_ERR_HIP         -2   /* HIP runtime error (message holds hipGetErrorString) */
+#define RAY_ERR_NOMEM       -3
+#define RAY_ERR_UNSUPPORTED -4
+
+/* per-ray status word (bit set).  The reference has no such word: a trapped ray loops forever
+ * (NonObstacle.jl:70, Obstacle.jl:27), bisections are uncapped (NonObstacle.jl:85,
+ * Obstacle.jl:48,77) and out-of-range cells are undefined behaviour under @inbounds.        */
+#define RAY_ST_EXITED      0x01  /* left the unit disk; exit point refined by bisection       */
+#define RAY_ST_STEP_CAP    0x02  /* max_steps reached                                         */
+#define RAY_ST_BISECT_CAP  0x04  /* a bisection hit RAY_BISECT_CAP iterations                 */
+#define RAY_ST_OOB         0x08  /* a table lookup left the valid cell range and was clamped  */
+#define RAY_ST_CEASED      0x10  /* fixed-time trace: left radius 1+2h and was ceased         */
+#define RAY_BISECT_CAP     200
+
+typedef struct ray_ctx    ray_ctx;     /* one per GPU */
+typedef struct ray_medium ray_medium;  /* wavespeed model resident in HBM */
+
+/* ---- context ------------------------------------------------------------------------- */
+int         ray_version(void);
+const char *ray_last_error(void);
+int         ray_device_count(int *n);
+int         ray_ctx_create(int device, ray_ctx **out);
+int         ray_ctx_destroy(ray_ctx *ctx);
+/* borrow a caller-owned hipStream_t (pass NULL to return to the context's own stream) */
+int         ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream);
+int         ray_ctx_synchronize(ray_ctx *ctx);
+
+/* out[k] = linspace(a, b, n)[k+1] exactly as the library (and Julia's TwicePrecision ranges,
+ * NonObstacle.jl:55-56,191) evaluates it: the correctly rounded a + k(b-a)/(n-1).  Host only;
+ * lets a caller fill c[i,j] = waveSpeed(p[i], p[j]) (NonObstacle.jl:306) on the same nodes.   */
+int         ray_linspace(double a, double b, int n, double *out);
+
+/* ---- media --------------------------------------------------------------------------- */
+/* Gridded medium.  Replaces the eval/grad SharedArray tables and their build loops
+ * (NonObstacle.jl:191-210, dup. Obstacle.jl:224-241, 277-294) and Q4 (NonObstacle.jl:103-105).
+ * c is copied; the caller keeps ownership.  N >= 4.                                          */
+int ray_medium_create_grid(ray_ctx *ctx, const double *c_host, int N, double ext, ray_medium **out);
+/* new nodal values, same N and ext: re-upload and rebuild the tables (one reconstruction
+ * iteration, NonObstacle.jl:333 -> :191-210).  _dev takes a device pointer, asynchronous.   */
+int ray_medium_update_grid(ray_medium *med, const double *c_host);
+int ray_medium_update_grid_dev(ray_medium *med, const double *c_dev);
+/* copy the tables back in the reference's layout: eval (N-1,N-1,4), grad (N-2,N-2,8),
+ * p (N) = linspace(-ext,ext,N); any pointer may be NULL.  For parity tests of the build.    */
+int ray_medium_export_tables(ray_medium *med, double *eval_host, double *grad_host, double *p_host);
+/* Analytic family  c = 1 + A sin(wx x) sin(wy y),  grad c = [gx cos(wx x) sin(wy y),
+ * gy sin(wx x) cos(wy y)].  NonObstacleDemo.jl:12,23 = (0.3, 1.5pi, 1.5pi, 0.45pi, 0.45pi);
+ * ObstacleDemo.jl:12,18 = (0.2, 2pi, pi, 2(0.2pi), 0.2pi).                                   */
+int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, double gx, double gy,
+                              ray_medium **out);
+int ray_medium_destroy(ray_medium *med);
+
+/* obstacle family (zero level set + normal).  CIRCLE: ob = sqrt(x^2+y^2) - r0, n = (x,y)/r
+ * renormalised (ObstacleDemo.jl:20-34).                                                      */
+#define RAY_OB_NONE   0
+#define RAY_OB_CIRCLE 1
+typedef struct { int32_t kind; int32_t pad_; double r0; double reserved[2]; } ray_obstacle;
+
+#define RAY_TIME_SECONDS 0   /* t += dt, exit correction t -= (1-mid)*dt  (NonObstacle.jl:77,90) */
+#define RAY_TIME_STEPS   1   /* t += 1,  exit correction t -= (1-mid)     (Obstacle.jl:39,53)    */
+
+typedef struct {
+    int32_t ns, nd;             /* boundary phase-space grid: ns sources x nd directions        */
+    int32_t src_begin, src_end; /* this call shoots sources [src_begin, src_end) (theta-block)  */
+    double  dir_lo, dir_hi;     /* direct = linspace(dir_lo, dir_hi, nd+2)[2:nd+1]              */
+    double  dt;                 /* RK4 step                                                    */
+    int32_t time_unit;          /* RAY_TIME_SECONDS | RAY_TIME_STEPS                           */
+    int32_t max_steps;          /* <=0 selects the default 1000000                             */
+} ray_shoot_params;
+
+/* ---- shooting to the boundary: ScatterRelation (NonObstacle.jl:54-99) and
+ *      ScatterRelationObstacle (Obstacle.jl:11-97; pass a CIRCLE obstacle and RAY_TIME_STEPS).
+ * m has (src_end-src_begin)*nd rows; row (i-src_begin)*nd + j is source i, direction j
+ * (NonObstacle.jl:63).  All nine columns are written.  status/nsteps/nreflect (int32 per row)
+ * may each be NULL.                                                                           */
+int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
+                      const ray_shoot_params *prm, double *m_host, int64_t ld,
+                      int32_t *status, int32_t *nsteps, int32_t *nreflect);
+int ray_shoot_to_exit_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
+                          const ray_shoot_params *prm, double *m_dev, int64_t ld,
+                          int32_t *status_dev, int32_t *nsteps_dev, int32_t *nreflect_dev);
+/* same loops from explicit initial states m[:,1:4] (the per-ray part, NonObstacle.jl:67-97 /
+ * Obstacle.jl:23-95); columns 5..9 are written.                                               */
+int ray_shoot_states(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt,
+                     int32_t time_unit, int32_t max_steps, double *m_host, int64_t num, int64_t ld,
+                     int32_t *status, int32_t *nsteps, int32_t *nreflect);
+int ray_shoot_states_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt,
+                         int32_t time_unit, int32_t max_steps, double *m_dev, int64_t num,
+                         int64_t ld, int32_t *status_dev, int32_t *nsteps_dev,
+                         int32_t *nreflect_dev);
+
+/* ---- fixed-time tracing on a gridded medium ------------------------------------------------
+ * RAY_TRACE_SHORTEN_CEASE : the X-trajectory of ChunkProcessing! (NonObstacle.jl:146-157,
+ *                           161-164,171,177-181,185) = the `s` output of ScatterForwardOperator
+ * RAY_TRACE_OVERSHOOT     : NonReflectionTrace (Obstacle.jl:306-326)
+ * Reads m[:,1:4] and T = m[:,9]; writes X_out (num,4) column-major with leading dim ldx.      */
+#define RAY_TRACE_SHORTEN_CEASE 0
+#define RAY_TRACE_OVERSHOOT     1
+int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num,
+                         int64_t ld, double dt, int32_t mode, double *X_host, int64_t ldx,
+                         int32_t *status, int32_t *nsteps);
+int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
+                             int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
+                             int32_t *status_dev, int32_t *nsteps_dev);
+
+/* ---- misfit (NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252) ------------------
+ * out[0] = sum_r,k (m[r,4+k]-obs[r,4+k])^2, out[1] = sum_r,k m[r,4+k]^2  (objective =
+ * sqrt(out[0]/out[1])); mask[r] = |m[r,5:8]-obs[r,5:8]| / |m[r,5:8]| < perc_thresh;
+ * mismatch[4r+k] ray-major as the reference's reshape of the transposed difference.
+ * mask and mismatch may be NULL.  Sums are reduced in a fixed, run-to-run reproducible tree
+ * order (differs from the reference's serial order by rounding only).                         */
+int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64_t num, int64_t ld,
+               double out[2], uint8_t *mask, double perc_thresh, double *mismatch);
+int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num,
+                   int64_t ld, double *out_dev, uint8_t *mask_dev, double perc_thresh,
+                   double *mismatch_dev);
+
+/* ---- counters (replaces the reference's tic/toq table, NonObstacle.jl:332-334) ------------- */
+typedef struct {
+    uint64_t rays;        /* rays integrated since reset                         */
+    uint64_t ray_steps;   /* RK4 steps taken by those rays                       */
+    uint64_t launches;    /* integration kernel launches                         */
+    double   kernel_ms;   /* summed HIP-event time of those launches (timing on) */
+} ray_counters;
+int ray_ctx_enable_timing(ray_ctx *ctx, int on);   /* record HIP events around each launch */
+int ray_get_counters(ray_ctx *ctx, ray_counters *out);   /* synchronizes the stream */
+int ray_reset_counters(ray_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAY_AMD_H */

@@ -1,0 +1,86 @@
+"""Generates tests/golden/*.npz from the pure-Python restatement (oracle/ray_oracle.py).
+
+Run from the repo root:  python oracle/gen_golden.py
+The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
+path to the Python reading of the reference; the reference itself ships no vectors
+("parity unpinned" by the reference).
+"""
+import os
+import sys
+from math import pi
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ray_oracle as P  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def pack(rows, out):
+    m = np.array([list(r) + list(o[0]) + [o[1]] for r, o in zip(rows, out)], dtype=np.float64)
+    return dict(m=m, status=np.array([o[2] for o in out], dtype=np.int32),
+                nsteps=np.array([o[3] for o in out], dtype=np.int32),
+                nreflect=np.array([o[4] for o in out], dtype=np.int32))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns, nd, dt = 8, 16, 1e-2
+
+    # G1a: smooth demo medium, analytic, ScatterRelation (NonObstacleDemo.jl:32)
+    sp = P.SinProd.smooth_demo()
+    rows = P.init_states(sp, ns, nd, 0.0, pi)
+    np.savez(os.path.join(OUT, "scatter_smooth_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt,
+             params=np.array([sp.A, sp.wx, sp.wy, sp.gx, sp.gy]), **pack(rows, P.shoot(sp, rows, dt)))
+
+    # G1b: obstacle demo medium + circle 0.3, ScatterRelationObstacle (ObstacleDemo.jl:43)
+    so = P.SinProd.obstacle_demo()
+    rows = P.init_states(so, ns, nd, 0.0, pi)
+    np.savez(os.path.join(OUT, "scatter_obstacle_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt, r0=0.3,
+             params=np.array([so.A, so.wx, so.wy, so.gx, so.gy]),
+             **pack(rows, P.shoot(so, rows, dt, obstacle=P.Circle(0.3), time_unit=1)))
+
+    # G1c: gridded N=75, ext=1.5 (NonObstacleDemo.jl:36): tables, shoot-to-exit on the grid,
+    #      then both fixed-time traces at the reconstruction step 5e-2 (NonObstacleDemo.jl:29)
+    N, ext = 75, 1.5
+    p = P.linspace(-ext, ext, N)
+    c = [sp.c(p[i], p[j]) for j in range(N) for i in range(N)]       # column-major, first index x
+    g = P.Grid(c, N, ext)
+    rows = P.init_states(g, ns, nd, 0.0, pi)
+    shot = P.shoot(g, rows, dt)
+    pk = pack(rows, shot)
+    T = [o[1] for o in shot]
+    tr0 = P.trace_fixed_time(g, rows, T, 5e-2, 0)
+    tr1 = P.trace_fixed_time(g, rows, T, 5e-2, 1)
+    ev = np.array([[g.ev[I, J] for J in range(1, N)] for I in range(1, N)])          # (N-1,N-1,4)
+    gr = np.array([[g.gr[I, J] for J in range(1, N - 1)] for I in range(1, N - 1)])  # (N-2,N-2,8)
+    np.savez(os.path.join(OUT, "grid_n75_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt, N=N, ext=ext,
+             c=np.array(c).reshape(N, N, order="F"), p=np.array(p), eval=ev, grad=gr,
+             trace_dt=5e-2,
+             X_shorten=np.array([o[0] for o in tr0]), st_shorten=np.array([o[1] for o in tr0], dtype=np.int32),
+             ns_shorten=np.array([o[2] for o in tr0], dtype=np.int32),
+             X_overshoot=np.array([o[0] for o in tr1]), st_overshoot=np.array([o[1] for o in tr1], dtype=np.int32),
+             ns_overshoot=np.array([o[2] for o in tr1], dtype=np.int32), **pk)
+
+    # G2: a5 tables for the N=8 grid of the same medium (SURVEY.md section 8c pin G2)
+    N2 = 8
+    p2 = P.linspace(-ext, ext, N2)
+    c2 = [sp.c(p2[i], p2[j]) for j in range(N2) for i in range(N2)]
+    g2 = P.Grid(c2, N2, ext)
+    ev2 = np.array([[g2.ev[I, J] for J in range(1, N2)] for I in range(1, N2)])
+    gr2 = np.array([[g2.gr[I, J] for J in range(1, N2 - 1)] for I in range(1, N2 - 1)])
+    np.savez(os.path.join(OUT, "tables_n8.npz"), N=N2, ext=ext, c=np.array(c2).reshape(N2, N2, order="F"),
+             p=np.array(p2), eval=ev2, grad=gr2)
+
+    # a11 misfit on the gridded case: data = shot, observation = SHORTEN_CEASE trace
+    m58 = [list(o[0]) for o in shot]
+    o58 = [list(o[0]) for o in tr0]
+    sm, st, mask = P.misfit(m58, o58, 0.2)
+    np.savez(os.path.join(OUT, "misfit_grid_n75.npz"), sum_mismatch2=sm, sum_target2=st,
+             mask=np.array(mask, dtype=np.uint8))
+    print("golden fixtures written to", os.path.normpath(OUT))
+
+
+if __name__ == "__main__":
+    main()

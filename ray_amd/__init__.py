@@ -1,0 +1,301 @@
+"""ray_amd -- MI355X-native forward ray-shooting core of lowrank/ray behind the reference's names.
+
+Host-side mirror of the reference's Julia entry points (Julia is not installed in this image;
+julia/RayAMD.jl is the ccall shim a Julia caller would use, this module is the same thing over
+ctypes).  Everything here calls libray_amd.so (include/ray_amd.h); nothing is computed on the
+CPU and there is no fallback.
+
+    reference (file:line)                          here
+    ScatterRelation          NonObstacle.jl:54     ScatterRelation(c, gradc, ns, nd, dt, dir)
+    ScatterRelationObstacle  Obstacle.jl:11        ScatterRelationObstacle(c, gradc, ob, gradob, ns, nd, dt)
+    ScatterForwardOperator   NonObstacle.jl:189    ScatterForwardOperator(c, m, ext, dt) -> (M, s)
+    NonReflectionTrace       Obstacle.jl:275       NonReflectionTrace(c, m, ext, dt)
+    mismatch/objective/perc  NonObstacle.jl:336,372; ObstacleDemo.jl:219-226   misfit(m, obs)
+
+Function-valued arguments cannot reach a GPU through a C ABI, so `c`/`gradc` are a medium
+descriptor (SinProd) and `ob`/`gradob` an obstacle descriptor (Circle); pass the same object (or
+None) for the gradient slot.  Arrays are numpy float64 in Fortran order, laid out like the
+reference's m / s / c.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import (RayError, ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED,
+                   TIME_SECONDS, TIME_STEPS, TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT)
+
+__all__ = ["Context", "SinProd", "Circle", "GridMedium", "ScatterRelation",
+           "ScatterRelationObstacle", "ScatterForwardOperator", "NonReflectionTrace", "misfit",
+           "RayError", "default_context"]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per GPU (ray_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.ray_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ray_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self._lib.ray_ctx_synchronize(self.handle))
+
+    def set_stream(self, hip_stream):
+        _lib.check(self._lib.ray_ctx_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.ray_ctx_enable_timing(self.handle, int(bool(on))))
+
+    def counters(self):
+        c = _lib.Counters()
+        _lib.check(self._lib.ray_get_counters(self.handle, C.byref(c)))
+        return {"rays": c.rays, "ray_steps": c.ray_steps, "launches": c.launches,
+                "kernel_ms": c.kernel_ms}
+
+    def reset_counters(self):
+        _lib.check(self._lib.ray_reset_counters(self.handle))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib.load().ray_device_count(C.byref(n))
+    return n.value
+
+
+class SinProd:
+    """c = 1 + A sin(wx x) sin(wy y); grad c = [gx cos(wx x) sin(wy y), gy sin(wx x) cos(wy y)]
+    -- the family both shipped demos use (NonObstacleDemo.jl:12,23; ObstacleDemo.jl:12,18)."""
+
+    def __init__(self, A, wx, wy, gx, gy):
+        self.params = (float(A), float(wx), float(wy), float(gx), float(gy))
+
+    @classmethod
+    def smooth_demo(cls):          # NonObstacleDemo.jl:12,23
+        return cls(0.3, 1.5 * math.pi, 1.5 * math.pi, 0.45 * math.pi, 0.45 * math.pi)
+
+    @classmethod
+    def obstacle_demo(cls):        # ObstacleDemo.jl:12,18
+        return cls(0.2, 2 * math.pi, math.pi, 2 * (0.2 * math.pi), 0.2 * math.pi)
+
+    def __call__(self, x, y):      # waveSpeed(x, y), for filling grids on the host
+        A, wx, wy, _, _ = self.params
+        return 1 + A * math.sin(wx * x) * math.sin(wy * y)
+
+    def _medium(self, ctx):
+        cache = self.__dict__.setdefault("_handles", {})
+        if id(ctx) not in cache:
+            cache[id(ctx)] = _Medium.sinprod(ctx, self.params)
+        return cache[id(ctx)]
+
+
+class Circle:
+    """ob = sqrt(x^2+y^2) - r0, normal (x,y)/r (ObstacleDemo.jl:20-34)."""
+
+    def __init__(self, r0):
+        self.r0 = float(r0)
+
+    def _struct(self):
+        return _lib.Obstacle(_lib.OB_CIRCLE, 0, self.r0, (C.c_double * 2)(0, 0))
+
+
+class _Medium:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    @classmethod
+    def sinprod(cls, ctx, params):
+        h = C.c_void_p()
+        _lib.check(ctx._lib.ray_medium_create_sinprod(ctx.handle, *params, C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            self.ctx._lib.ray_medium_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GridMedium(_Medium):
+    """Nodal wavespeed c (N,N) on linspace(-ext,ext,N)^2, first index x (NonObstacle.jl:306);
+    owns the eval/grad tables of NonObstacle.jl:191-210 in HBM."""
+
+    def __init__(self, c, ext, ctx=None):
+        ctx = ctx or default_context()
+        c = np.asfortranarray(c, dtype=np.float64)
+        if c.ndim != 2 or c.shape[0] != c.shape[1]:
+            raise ValueError("c must be square (N,N)")
+        h = C.c_void_p()
+        _lib.check(ctx._lib.ray_medium_create_grid(ctx.handle, _ptr(c), c.shape[0], float(ext),
+                                                   C.byref(h)))
+        super().__init__(ctx, h)
+        self.N, self.ext = c.shape[0], float(ext)
+
+    def update(self, c):
+        c = np.asfortranarray(c, dtype=np.float64)
+        if c.shape != (self.N, self.N):
+            raise ValueError("shape mismatch")
+        _lib.check(self.ctx._lib.ray_medium_update_grid(self.handle, _ptr(c)))
+
+    def tables(self):
+        """(eval (N-1,N-1,4), grad (N-2,N-2,8), p (N)) in the reference's layout."""
+        N = self.N
+        ev = np.zeros((N - 1, N - 1, 4), order="F")
+        gr = np.zeros((N - 2, N - 2, 8), order="F")
+        p = np.zeros(N)
+        _lib.check(self.ctx._lib.ray_medium_export_tables(self.handle, _ptr(ev), _ptr(gr), _ptr(p)))
+        return ev, gr, p
+
+    def _medium(self, ctx):
+        if ctx is not self.ctx:
+            raise RayError("grid medium belongs to another context")
+        return self
+
+
+def _resolve(c, gradc, ctx):
+    if gradc is not None and gradc is not c:
+        raise RayError("pass the medium descriptor itself (or None) as its gradient: closures "
+                       "cannot cross the C ABI onto the GPU")
+    if not hasattr(c, "_medium"):
+        raise RayError("c must be a SinProd or GridMedium descriptor, not a Python function")
+    return c._medium(ctx)
+
+
+def _shoot(med, ob, ns, nd, dt, dir_, time_unit, ctx, src_begin, src_end, max_steps, info):
+    src_end = ns if src_end is None else src_end
+    num = (src_end - src_begin) * nd
+    m = np.zeros((num, 9), dtype=np.float64, order="F")
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    nrf = np.zeros(num, dtype=np.int32)
+    prm = _lib.ShootParams(ns, nd, src_begin, src_end, float(dir_[0]), float(dir_[1]), float(dt),
+                           time_unit, max_steps)
+    obs = ob._struct() if ob is not None else None
+    _lib.check(ctx._lib.ray_shoot_to_exit(ctx.handle, med.handle, C.byref(obs) if obs else None,
+                                          C.byref(prm), _ptr(m), max(num, 1), _ptr(st), _ptr(nst),
+                                          _ptr(nrf)))
+    if info:
+        return m, {"status": st, "nsteps": nst, "nreflect": nrf}
+    return m
+
+
+def ScatterRelation(c, gradc, ns, nd, dt, dir=(0.0, math.pi), *, ctx=None, src_begin=0,
+                    src_end=None, max_steps=0, info=False):
+    """NonObstacle.jl:54-99.  Returns m (ns*nd, 9), t in seconds."""
+    ctx = ctx or default_context()
+    return _shoot(_resolve(c, gradc, ctx), None, ns, nd, dt, dir, TIME_SECONDS, ctx, src_begin,
+                  src_end, max_steps, info)
+
+
+def ScatterRelationObstacle(c, gradc, ob, gradob, ns, nd, dt, *, ctx=None, src_begin=0,
+                            src_end=None, max_steps=0, info=False):
+    """Obstacle.jl:11-97.  Column 9 counts steps (the caller rescales, ObstacleDemo.jl:122)."""
+    ctx = ctx or default_context()
+    if gradob is not None and gradob is not ob:
+        raise RayError("pass the obstacle descriptor itself (or None) as its normal")
+    return _shoot(_resolve(c, gradc, ctx), ob, ns, nd, dt, (0.0, math.pi), TIME_STEPS, ctx,
+                  src_begin, src_end, max_steps, info)
+
+
+def shoot_states(c, m, dt, ob=None, time_unit=TIME_SECONDS, *, ctx=None, max_steps=0):
+    """Per-ray loops of ScatterRelation / ScatterRelationObstacle from explicit m[:,1:4]
+    (NonObstacle.jl:67-97; Obstacle.jl:23-95).  In place; returns info dict."""
+    ctx = ctx or default_context()
+    med = _resolve(c, None, ctx)
+    if not (m.flags.f_contiguous and m.dtype == np.float64 and m.ndim == 2 and m.shape[1] == 9):
+        raise ValueError("m must be float64 Fortran-ordered (num, 9)")
+    num = m.shape[0]
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    nrf = np.zeros(num, dtype=np.int32)
+    obs = ob._struct() if ob is not None else None
+    _lib.check(ctx._lib.ray_shoot_states(ctx.handle, med.handle, C.byref(obs) if obs else None,
+                                         float(dt), time_unit, max_steps, _ptr(m), num, max(num, 1),
+                                         _ptr(st), _ptr(nst), _ptr(nrf)))
+    return {"status": st, "nsteps": nst, "nreflect": nrf}
+
+
+def _trace(c, m, ext, dt, mode, ctx, info):
+    ctx = ctx or default_context()
+    med = c if isinstance(c, GridMedium) else GridMedium(c, ext, ctx)
+    m = np.asfortranarray(m, dtype=np.float64)
+    num = m.shape[0]
+    X = np.zeros((num, 4), dtype=np.float64, order="F")
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    _lib.check(ctx._lib.ray_trace_fixed_time(ctx.handle, med.handle, _ptr(m), num, max(num, 1),
+                                             float(dt), mode, _ptr(X), max(num, 1), _ptr(st),
+                                             _ptr(nst)))
+    return X, {"status": st, "nsteps": nst}
+
+
+def ScatterForwardOperator(c, m, ext, dt, *, ctx=None, info=False):
+    """NonObstacle.jl:189-243, ray-trajectory part: returns (M, s) with s[:,1:4], s[:,9] copied
+    from m (:196) and s[:,5:8] the traced end states (:185).  M -- the Frechet matrix -- is the
+    NEXT-1 row of SURVEY.md section 8f and is returned as None in this round."""
+    X, inf = _trace(c, m, ext, dt, TRACE_SHORTEN_CEASE, ctx, info)
+    s = np.zeros((m.shape[0], 9), dtype=np.float64, order="F")
+    s[:, 0:4] = m[:, 0:4]
+    s[:, 8] = m[:, 8]
+    s[:, 4:8] = X
+    return (None, s, inf) if info else (None, s)
+
+
+def NonReflectionTrace(c, m, ext, dt, *, ctx=None, info=False):
+    """Obstacle.jl:275-329: m with columns 5..8 overwritten by the fixed-time end states."""
+    X, inf = _trace(c, m, ext, dt, TRACE_OVERSHOOT, ctx, info)
+    out = np.array(m, dtype=np.float64, order="F", copy=True)
+    out[:, 4:8] = X
+    return (out, inf) if info else out
+
+
+def misfit(m, obs, perc_thresh=0.2, *, ctx=None):
+    """NonObstacle.jl:336,372; ObstacleDemo.jl:219-226.  Returns dict with `mismatch` (4*num,
+    ray-major), `sum_mismatch2`, `sum_target2`, `objective`, `mask` (perc < perc_thresh)."""
+    ctx = ctx or default_context()
+    m = np.asfortranarray(m, dtype=np.float64)
+    obs = np.asfortranarray(obs, dtype=np.float64)
+    if m.shape != obs.shape or m.shape[1] != 9:
+        raise ValueError("m and obs must both be (num, 9)")
+    num = m.shape[0]
+    out = np.zeros(2)
+    mask = np.zeros(num, dtype=np.uint8)
+    mism = np.zeros(4 * num)
+    _lib.check(ctx._lib.ray_misfit(ctx.handle, _ptr(m), _ptr(obs), num, max(num, 1), _ptr(out),
+                                   _ptr(mask), float(perc_thresh), _ptr(mism)))
+    return {"mismatch": mism, "sum_mismatch2": out[0], "sum_target2": out[1],
+            "objective": math.sqrt(out[0] / out[1]) if out[1] > 0 else float("nan"),
+            "mask": mask}

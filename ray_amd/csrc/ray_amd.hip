@@ -1,0 +1,944 @@
+// ray_amd.hip -- kernels + C ABI of libray_amd.so (see include/ray_amd.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (ray_amd/csrc/Makefile)
+#include "../../include/ray_amd.h"
+#include "ray_device.h"
+#include "ray_host_math.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace ray;
+
+// =============================================================================================
+// kernels
+// =============================================================================================
+
+// a4 + a5: Q4 and the eval/grad table build (NonObstacle.jl:103-105, 191-210), one thread per
+// cell, written as one 96-byte record (ray_device.h).  True IEEE divisions, reference order.
+__device__ __forceinline__ void q4(const double *c, int N, int i, int j, double dx, double q[4])
+{
+    const double c00 = c[(size_t)i + (size_t)j * N], c10 = c[(size_t)i + 1 + (size_t)j * N];
+    const double c01 = c[(size_t)i + (size_t)(j + 1) * N], c11 = c[(size_t)i + 1 + (size_t)(j + 1) * N];
+    q[0] = c00;
+    q[1] = (c10 - c00) / dx;
+    q[2] = (c01 - c00) / dx;
+    q[3] = (((c11 + c00) - c10) - c01) / (dx * dx);
+}
+
+__global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__ c, int N, double dx,
+                                                       double *__restrict__ rec)
+{
+    const int n1 = N - 1;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n1 * n1) return;
+    const int i = (int)(id % n1), j = (int)(id / n1);          // cell (I,J) = (i+1, j+1)
+    double out[12];
+    q4(c, N, i, j, dx, out);
+#pragma unroll
+    for (int k = 4; k < 12; ++k) out[k] = 0.0;                   // never written in the reference
+    if (i >= 1 && i <= N - 3 && j >= 1 && j <= N - 3) {          // I,J in 2..N-2
+        double a[4], b[4];
+        const double two_dx = 2 * dx;
+        q4(c, N, i + 1, j, dx, a);
+        q4(c, N, i - 1, j, dx, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[4 + k] = (a[k] - b[k]) / two_dx;
+        q4(c, N, i, j + 1, dx, a);
+        q4(c, N, i, j - 1, dx, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[8 + k] = (a[k] - b[k]) / two_dx;
+    }
+    double2 *r = reinterpret_cast<double2 *>(rec) + (size_t)id * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = make_double2(out[2 * k], out[2 * k + 1]);
+}
+
+struct ShootArgs {
+    MediumDev med;
+    int ob_kind;
+    double ob_r0;
+    // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
+    int init;
+    int nd;
+    const double *src;      // source[i]            (local index i - src_begin)
+    const double *src_cos;  // cos(source[i])  host libm
+    const double *src_sin;  // sin(source[i])
+    const double *direct;   // direct[j], j = 0..nd-1
+    double half_pi;         // Float64(pi) * 0.5
+    double dt;
+    int time_unit;
+    int max_steps;
+    double *m;
+    int64_t num, ld;
+    int32_t *status, *nsteps, *nreflect;
+    unsigned long long *step_counter;
+};
+
+__device__ __forceinline__ double ob_val(double r0, double x, double y) { return norm2(x, y) - r0; }
+
+// a6 / a7: ScatterRelation / ScatterRelationObstacle per-ray loop.
+// NonObstacle.jl:67-97; Obstacle.jl:23-95.  Lanes = consecutive directions of one source, so a
+// wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
+// The exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
+// wavefront has left the disk and is then run by all lanes at once.
+template <int MED, int OB>
+__global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = r < a.num;
+    double X[4] = {0, 0, 0, 0}, P[4] = {0, 0, 0, 0};
+    int st = 0, oob = 0;
+    if (valid) {
+        if (a.init) {
+            const int64_t il = r / a.nd;
+            const int j = (int)(r - il * a.nd);
+            const double sx = a.src_cos[il], sy = a.src_sin[il];
+            const double theta = a.src[il] + a.half_pi + a.direct[j];
+            double sn, cs;
+            sincos(theta, &sn, &cs);
+            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, sx, sy, oob)
+                                             : speed_sinprod(a.med.sp, sx, sy);
+            X[0] = sx; X[1] = sy; X[2] = cs / c0; X[3] = sn / c0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.m[r + k * a.ld] = X[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
+        }
+    }
+    double t = 0;
+    int steps = 0, nref = 0, rfl = 0;
+    bool active = valid;
+    const double dt = a.dt;
+    while (active) {
+        if (OB == kObCircle) { if (ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[k] = X[k];
+        rk4_kdt<MED>(a.med, X, dt, oob);
+        ++steps;
+        t = a.time_unit ? t + 1 : t + dt;
+        // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
+        const double s = X[0] * X[0] + X[1] * X[1];
+        if (s >= 1.0) { st |= kStExited; active = false; }
+        else {
+            if (OB == kObCircle) {
+                if (ob_val(a.ob_r0, X[0], X[1]) <= 0 && rfl == 0) {              // Obstacle.jl:69-91
+                    double lo = 0, hi = 1, mid = 0.5, E[4], e;
+                    int it = 0;
+                    rfl = 1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+                    e = ob_val(a.ob_r0, E[0], E[1]);
+                    while (__builtin_fabs(e) > 1e-15) {
+                        if (++it > kBisectCap) { st |= kStBisectCap; break; }
+                        if (e > 0) lo = mid; else hi = mid;
+                        mid = (lo + hi) * 0.5;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+                        e = ob_val(a.ob_r0, E[0], E[1]);
+                    }
+                    // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
+                    const double rr = norm2(E[0], E[1]);
+                    double nx = E[0] / rr, ny = E[1] / rr;
+                    const double nn = norm2(nx, ny);
+                    nx = nx / nn; ny = ny / nn;
+                    const double a0 = 2 * nx, a1 = 2 * ny;
+                    const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
+                    const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
+                    X[0] = E[0]; X[1] = E[1];
+                    X[2] = m11 * E[2] + m12 * E[3];
+                    X[3] = m21 * E[2] + m22 * E[3];
+                    ++nref;
+                }
+            }
+            if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
+        }
+    }
+    if (st & kStExited) {                                       // NonObstacle.jl:82-91
+        double lo = 0, hi = 1, mid = 0.5, E[4], e;
+        int it = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+        e = norm2(E[0], E[1]) - 1;
+        while (__builtin_fabs(e) > 1e-15) {
+            if (++it > kBisectCap) { st |= kStBisectCap; break; }
+            if (e > 0) hi = mid; else lo = mid;
+            mid = (lo + hi) * 0.5;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+            e = norm2(E[0], E[1]) - 1;
+        }
+        t = a.time_unit ? t - (1 - mid) : t - (1 - mid) * dt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = E[k];
+    }
+    if (oob) st |= kStOob;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];
+        a.m[r + 8 * a.ld] = t;
+        if (a.status) a.status[r] = st;
+        if (a.nsteps) a.nsteps[r] = steps;
+        if (a.nreflect) a.nreflect[r] = nref;
+    }
+    const unsigned wsum = wave_sum((unsigned)steps);
+    if ((threadIdx.x & 63) == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+}
+
+struct TraceArgs {
+    MediumDev med;
+    const double *m;
+    int64_t num, ld;
+    double dt;
+    int mode;
+    double cease_r;       // 1 + 2*(p[2]-p[1])                      NonObstacle.jl:177
+    int max_steps;
+    double *X;
+    int64_t ldx;
+    int32_t *status, *nsteps;
+    unsigned long long *step_counter;
+};
+
+// a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
+// NonObstacle.jl:146-157,161-164,171,177-181,185).
+__global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = r < a.num;
+    double X[4] = {0, 0, 0, 0};
+    double T = 0;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
+        T = a.m[r + 8 * a.ld];
+    }
+    double t = 0, dt = a.dt;
+    int steps = 0, st = 0, oob = 0;
+    while (valid && t < T) {
+        if (steps >= a.max_steps) { st |= kStStepCap; break; }
+        if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;
+        t = t + dt;
+        rk4_k<kGrid>(a.med, X, dt, oob);
+        ++steps;
+        if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
+            // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
+            // threshold; outside it the squared comparison decides with certainty.
+            const double s = X[0] * X[0] + X[1] * X[1];
+            const double c2 = a.cease_r * a.cease_r;
+            bool out;
+            if (s > c2 * 1.0000000001) out = true;
+            else if (s < c2 * 0.9999999999) out = false;
+            else out = __builtin_sqrt(s) > a.cease_r;
+            if (out) { t = t + (T - t); st |= kStCeased; }
+        }
+    }
+    if (oob) st |= kStOob;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.X[r + k * a.ldx] = X[k];
+        if (a.status) a.status[r] = st;
+        if (a.nsteps) a.nsteps[r] = steps;
+    }
+    const unsigned wsum = wave_sum((unsigned)steps);
+    if ((threadIdx.x & 63) == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+}
+
+// a11: misfit sums, per-ray selection mask, ray-major mismatch vector.
+// Stage 1: fixed grid of kMisfitBlocks x 256 threads, grid-stride over rays, LDS tree per block.
+// Stage 2: one block folds the kMisfitBlocks partials.  Order is fixed -> reproducible.
+constexpr int kMisfitBlocks = 1024;
+
+__device__ __forceinline__ void block_tree_sum2(double &u, double &v, double *lds)
+{
+    const int tid = threadIdx.x;
+    lds[tid] = u;
+    lds[256 + tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { lds[tid] = lds[tid] + lds[tid + o]; lds[256 + tid] = lds[256 + tid] + lds[256 + tid + o]; }
+        __syncthreads();
+    }
+    u = lds[0];
+    v = lds[256];
+}
+
+__global__ __launch_bounds__(256) void k_misfit_partial(const double *__restrict__ m,
+                                                         const double *__restrict__ obs, int64_t num,
+                                                         int64_t ld, double thresh,
+                                                         uint8_t *__restrict__ mask,
+                                                         double *__restrict__ mismatch,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double lds[512];
+    double sm = 0, stg = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < num; r += (int64_t)gridDim.x * 256) {
+        double d[4], a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = m[r + (4 + k) * ld];
+            d[k] = a[k] - obs[r + (4 + k) * ld];
+            sm = sm + d[k] * d[k];
+            stg = stg + a[k] * a[k];
+        }
+        if (mismatch) {
+            double2 *o = reinterpret_cast<double2 *>(mismatch + 4 * r);
+            o[0] = make_double2(d[0], d[1]);
+            o[1] = make_double2(d[2], d[3]);
+        }
+        if (mask) {
+            const double nd_ = __builtin_sqrt(((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]);
+            const double na = __builtin_sqrt(((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]) + a[3] * a[3]);
+            mask[r] = (nd_ / na < thresh) ? 1 : 0;
+        }
+    }
+    block_tree_sum2(sm, stg, lds);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = sm; partial[kMisfitBlocks + blockIdx.x] = stg; }
+}
+
+__global__ __launch_bounds__(256) void k_misfit_final(const double *__restrict__ partial,
+                                                       double *__restrict__ out)
+{
+    __shared__ double lds[512];
+    double sm = 0, stg = 0;
+    for (int k = threadIdx.x; k < kMisfitBlocks; k += 256) {
+        sm = sm + partial[k];
+        stg = stg + partial[kMisfitBlocks + k];
+    }
+    block_tree_sum2(sm, stg, lds);
+    if (threadIdx.x == 0) { out[0] = sm; out[1] = stg; }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RAY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+struct InitTables;
+struct ray_ctx {
+    int device = 0;
+    InitTables *init = nullptr;                // cached boundary-grid tables
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long *d_steps = nullptr;     // device ray-step counter
+    double *d_partial = nullptr;               // misfit partials, 2*kMisfitBlocks
+    uint64_t rays = 0, launches = 0;
+    bool timing = false;
+    double kernel_ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct ray_medium {
+    ray_ctx *ctx = nullptr;
+    int kind = kSinProd;
+    SinProdDev sp{};
+    int N = 0;
+    double ext = 0;
+    double *d_c = nullptr, *d_rec = nullptr, *d_p = nullptr;
+    std::vector<double> p;                     // host copy of the nodes
+};
+
+struct DevBuf {                                // scoped device allocation for host-pointer calls
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+static int use(ray_ctx *ctx)
+{
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(ctx->device));
+    return RAY_OK;
+}
+
+static void time_begin(ray_ctx *ctx, hipEvent_t &e0, hipEvent_t &e1)
+{
+    e0 = e1 = nullptr;
+    if (!ctx->timing) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, ctx->stream);
+}
+static void time_end(ray_ctx *ctx, hipEvent_t e0, hipEvent_t e1)
+{
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->pending.emplace_back(e0, e1);
+}
+static void drain_timing(ray_ctx *ctx)
+{
+    for (auto &pr : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->kernel_ms += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->pending.clear();
+}
+
+// the device-side staging of the boundary grid: source angles, their libm cos/sin, directions.
+// Cached on the context and rebuilt only when the (ns, nd, dir, theta-block) key changes, so a
+// reconstruction loop / sweep that re-shoots the same grid uploads nothing.
+struct InitTables {
+    DevBuf src, cs, sn, dir;
+    int ns = -1, nd = -1, b = -1, e = -1;
+    double lo = 0, hi = 0;
+    bool matches(const ray_shoot_params *p) const
+    {
+        return ns == p->ns && nd == p->nd && b == p->src_begin && e == p->src_end && lo == p->dir_lo && hi == p->dir_hi;
+    }
+    int upload(ray_ctx *ctx, const ray_shoot_params *p)
+    {
+        const int nloc = p->src_end - p->src_begin;
+        std::vector<double> source(p->ns + 1), direct(p->nd + 2);
+        hostmath::linspace(0.0, 2 * M_PI, p->ns + 1, source.data());      // NonObstacle.jl:55
+        hostmath::linspace(p->dir_lo, p->dir_hi, p->nd + 2, direct.data()); // NonObstacle.jl:56
+        std::vector<double> s(nloc), c(nloc), sn_(nloc);
+        for (int i = 0; i < nloc; ++i) {
+            s[i] = source[p->src_begin + i];
+            c[i] = std::cos(s[i]);                                        // NonObstacle.jl:57
+            sn_[i] = std::sin(s[i]);
+        }
+        HIPCHK(src.alloc(sizeof(double) * nloc));
+        HIPCHK(cs.alloc(sizeof(double) * nloc));
+        HIPCHK(sn.alloc(sizeof(double) * nloc));
+        HIPCHK(dir.alloc(sizeof(double) * p->nd));
+        HIPCHK(hipMemcpyAsync(src.p, s.data(), sizeof(double) * nloc, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(cs.p, c.data(), sizeof(double) * nloc, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(sn.p, sn_.data(), sizeof(double) * nloc, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dir.p, direct.data() + 1, sizeof(double) * p->nd, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ns = p->ns; nd = p->nd; b = p->src_begin; e = p->src_end; lo = p->dir_lo; hi = p->dir_hi;
+        return RAY_OK;
+    }
+};
+
+static int init_tables(ray_ctx *ctx, const ray_shoot_params *p, InitTables **out)
+{
+    if (ctx->init && ctx->init->matches(p)) { *out = ctx->init; return RAY_OK; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // a launch may still read the old tables
+    delete ctx->init;
+    ctx->init = new InitTables;
+    int rc = ctx->init->upload(ctx, p);
+    if (rc) { delete ctx->init; ctx->init = nullptr; return rc; }
+    *out = ctx->init;
+    return RAY_OK;
+}
+
+extern "C" {
+
+int ray_version(void) { return 100; }
+const char *ray_last_error(void) { return g_err.c_str(); }
+
+int ray_linspace(double a, double b, int n, double *out)
+{
+    if (!out || n < 1) return fail(RAY_ERR_INVALID, "linspace needs n >= 1 and an output buffer");
+    hostmath::linspace(a, b, n, out);
+    return RAY_OK;
+}
+
+int ray_device_count(int *n)
+{
+    if (!n) return fail(RAY_ERR_INVALID, "null n");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(RAY_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+    return RAY_OK;
+}
+
+int ray_ctx_create(int device, ray_ctx **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    int rc = ray_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return fail(RAY_ERR_INVALID, "device index out of range (no GPU visible?)");
+    HIPCHK(hipSetDevice(device));
+    ray_ctx *c = new ray_ctx;
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_steps, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_steps, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_partial, sizeof(double) * 2 * kMisfitBlocks);
+    if (e != hipSuccess) {
+        std::string msg = std::string("ray_ctx_create: ") + hipGetErrorString(e);
+        ray_ctx_destroy(c);
+        return fail(RAY_ERR_HIP, msg);
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RAY_OK;
+}
+
+int ray_ctx_destroy(ray_ctx *ctx)
+{
+    if (!ctx) return RAY_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drain_timing(ctx);
+    delete ctx->init;
+    if (ctx->d_steps) (void)hipFree(ctx->d_steps);
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RAY_OK;
+}
+
+int ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return RAY_OK;
+}
+
+int ray_ctx_synchronize(ray_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- media ------------------------------------------------------------------------------------
+static int build_tables(ray_medium *med)
+{
+    ray_ctx *ctx = med->ctx;
+    const int n1 = med->N - 1;
+    const int64_t cells = (int64_t)n1 * n1;
+    const double dx = 2 * med->ext / (med->N - 1);                      // NonObstacle.jl:191
+    hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                       med->d_c, med->N, dx, med->d_rec);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_medium_create_grid(ray_ctx *ctx, const double *c_host, int N, double ext, ray_medium **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!c_host || N < 4 || !(ext > 0)) return fail(RAY_ERR_INVALID, "grid medium needs c, N >= 4, ext > 0");
+    ray_medium *m = new ray_medium;
+    m->ctx = ctx; m->kind = kGrid; m->N = N; m->ext = ext;
+    m->p.resize(N);
+    hostmath::linspace(-ext, ext, N, m->p.data());                     // NonObstacle.jl:191
+    const size_t nc = (size_t)N * N, nr = (size_t)(N - 1) * (N - 1) * 12;
+    hipError_t e = hipMalloc((void **)&m->d_c, nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_rec, nr * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_p, (size_t)N * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(m->d_p, m->p.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        std::string msg = std::string("ray_medium_create_grid: ") + hipGetErrorString(e);
+        ray_medium_destroy(m);
+        return fail(e == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, msg);
+    }
+    rc = ray_medium_update_grid(m, c_host);
+    if (rc) { ray_medium_destroy(m); return rc; }
+    *out = m;
+    return RAY_OK;
+}
+
+int ray_medium_update_grid(ray_medium *med, const double *c_host)
+{
+    if (!med || med->kind != kGrid || !c_host) return fail(RAY_ERR_INVALID, "update_grid: not a grid medium / null c");
+    int rc = use(med->ctx);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(med->d_c, c_host, (size_t)med->N * med->N * sizeof(double), hipMemcpyHostToDevice, med->ctx->stream));
+    rc = build_tables(med);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(med->ctx->stream));                     // c_host may be reused on return
+    return RAY_OK;
+}
+
+int ray_medium_update_grid_dev(ray_medium *med, const double *c_dev)
+{
+    if (!med || med->kind != kGrid || !c_dev) return fail(RAY_ERR_INVALID, "update_grid_dev: not a grid medium / null c");
+    int rc = use(med->ctx);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(med->d_c, c_dev, (size_t)med->N * med->N * sizeof(double), hipMemcpyDeviceToDevice, med->ctx->stream));
+    return build_tables(med);
+}
+
+int ray_medium_export_tables(ray_medium *med, double *eval_host, double *grad_host, double *p_host)
+{
+    if (!med || med->kind != kGrid) return fail(RAY_ERR_INVALID, "export_tables: not a grid medium");
+    int rc = use(med->ctx);
+    if (rc) return rc;
+    const int N = med->N;
+    const int64_t n1 = N - 1, n2 = N - 2;
+    std::vector<double> rec((size_t)n1 * n1 * 12);
+    HIPCHK(hipMemcpyAsync(rec.data(), med->d_rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost, med->ctx->stream));
+    HIPCHK(hipStreamSynchronize(med->ctx->stream));
+    if (eval_host)
+        for (int64_t j = 0; j < n1; ++j)
+            for (int64_t i = 0; i < n1; ++i)
+                for (int k = 0; k < 4; ++k)
+                    eval_host[i + j * n1 + k * n1 * n1] = rec[(size_t)(i + j * n1) * 12 + k];
+    if (grad_host)
+        for (int64_t j = 0; j < n2; ++j)
+            for (int64_t i = 0; i < n2; ++i)
+                for (int k = 0; k < 8; ++k)
+                    grad_host[i + j * n2 + k * n2 * n2] = rec[(size_t)(i + j * n1) * 12 + 4 + k];
+    if (p_host) std::memcpy(p_host, med->p.data(), (size_t)N * sizeof(double));
+    return RAY_OK;
+}
+
+int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, double gx, double gy, ray_medium **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    ray_medium *m = new ray_medium;
+    m->ctx = ctx; m->kind = kSinProd;
+    m->sp = SinProdDev{A, wx, wy, gx, gy};
+    *out = m;
+    return RAY_OK;
+}
+
+int ray_medium_destroy(ray_medium *med)
+{
+    if (!med) return RAY_OK;
+    if (med->ctx) { (void)hipSetDevice(med->ctx->device); (void)hipStreamSynchronize(med->ctx->stream); }
+    if (med->d_c) (void)hipFree(med->d_c);
+    if (med->d_rec) (void)hipFree(med->d_rec);
+    if (med->d_p) (void)hipFree(med->d_p);
+    delete med;
+    return RAY_OK;
+}
+
+static MediumDev medium_dev(const ray_medium *m)
+{
+    MediumDev d{};
+    d.sp = m->sp;
+    if (m->kind == kGrid) {
+        d.g.rec = m->d_rec; d.g.p = m->d_p; d.g.N = m->N;
+        d.g.p1 = m->p[0];
+        d.g.h = m->p[1] - m->p[0];                                      // NonObstacle.jl:32
+        d.g.rh = 1.0 / d.g.h;
+    }
+    return d;
+}
+
+// ---- shooting -----------------------------------------------------------------------------------
+static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, ShootArgs &a)
+{
+    const int obk = ob ? ob->kind : RAY_OB_NONE;
+    if (obk != RAY_OB_NONE && obk != RAY_OB_CIRCLE) return fail(RAY_ERR_UNSUPPORTED, "unknown obstacle kind");
+    if (obk == RAY_OB_CIRCLE && !(ob->r0 > 0)) return fail(RAY_ERR_INVALID, "circle obstacle needs r0 > 0");
+    a.med = medium_dev(med);
+    a.ob_kind = obk;
+    a.ob_r0 = ob ? ob->r0 : 0.0;
+    a.step_counter = ctx->d_steps;
+    if (a.max_steps <= 0) a.max_steps = 1000000;
+    if (a.num == 0) return RAY_OK;
+    const dim3 grid((unsigned)((a.num + 255) / 256)), block(256);
+    hipEvent_t e0, e1;
+    time_begin(ctx, e0, e1);
+    if (med->kind == kGrid) {
+        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kGrid, kObNone>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle>), grid, block, 0, ctx->stream, a);
+    } else {
+        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle>), grid, block, 0, ctx->stream, a);
+    }
+    time_end(ctx, e0, e1);
+    HIPCHK(hipGetLastError());
+    ctx->rays += (uint64_t)a.num;
+    ctx->launches += 1;
+    return RAY_OK;
+}
+
+static int check_med(ray_ctx *ctx, const ray_medium *med)
+{
+    if (!med) return fail(RAY_ERR_INVALID, "null medium");
+    if (med->ctx != ctx) return fail(RAY_ERR_INVALID, "medium belongs to another context");
+    return RAY_OK;
+}
+
+static int check_params(const ray_shoot_params *p)
+{
+    if (!p) return fail(RAY_ERR_INVALID, "null params");
+    if (p->ns < 1 || p->nd < 1) return fail(RAY_ERR_INVALID, "ns, nd must be >= 1");
+    if (p->src_begin < 0 || p->src_end > p->ns || p->src_begin > p->src_end)
+        return fail(RAY_ERR_INVALID, "need 0 <= src_begin <= src_end <= ns");
+    if (!(p->dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    if (p->time_unit != RAY_TIME_SECONDS && p->time_unit != RAY_TIME_STEPS) return fail(RAY_ERR_INVALID, "bad time_unit");
+    return RAY_OK;
+}
+
+static int shoot_to_exit_impl(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
+                              const ray_shoot_params *prm, double *m_dev, int64_t ld,
+                              int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    const int64_t num = (int64_t)(prm->src_end - prm->src_begin) * prm->nd;
+    if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
+    InitTables *tab = nullptr;
+    int rc = init_tables(ctx, prm, &tab);
+    if (rc) return rc;
+    ShootArgs a{};
+    a.init = 1; a.nd = prm->nd;
+    a.src = tab->src.as<double>(); a.src_cos = tab->cs.as<double>(); a.src_sin = tab->sn.as<double>();
+    a.direct = tab->dir.as<double>();
+    a.half_pi = M_PI * 0.5;
+    a.dt = prm->dt; a.time_unit = prm->time_unit; a.max_steps = prm->max_steps;
+    a.m = m_dev; a.num = num; a.ld = ld;
+    a.status = status; a.nsteps = nsteps; a.nreflect = nreflect;
+    return launch_shoot(ctx, med, ob, a);
+}
+
+int ray_shoot_to_exit_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
+                          const ray_shoot_params *prm, double *m_dev, int64_t ld,
+                          int32_t *status_dev, int32_t *nsteps_dev, int32_t *nreflect_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med)) || (rc = check_params(prm))) return rc;
+    if (!m_dev) return fail(RAY_ERR_INVALID, "null m");
+    return shoot_to_exit_impl(ctx, med, ob, prm, m_dev, ld, status_dev, nsteps_dev, nreflect_dev);
+}
+
+static int copy_cols_h2d(ray_ctx *ctx, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int c0, int ncol)
+{
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)c0 * ldd, (size_t)ldd * 8, src + (size_t)c0 * lds, (size_t)lds * 8,
+                            (size_t)rows * 8, (size_t)ncol, hipMemcpyHostToDevice, ctx->stream));
+    return RAY_OK;
+}
+static int copy_cols_d2h(ray_ctx *ctx, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int c0, int ncol)
+{
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)c0 * ldd, (size_t)ldd * 8, src + (size_t)c0 * lds, (size_t)lds * 8,
+                            (size_t)rows * 8, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+    return RAY_OK;
+}
+
+struct RayOutBufs {
+    DevBuf st, ns, nr;
+    int alloc(int64_t num) {
+        HIPCHK(st.alloc(sizeof(int32_t) * (size_t)num));
+        HIPCHK(ns.alloc(sizeof(int32_t) * (size_t)num));
+        HIPCHK(nr.alloc(sizeof(int32_t) * (size_t)num));
+        return RAY_OK;
+    }
+    int fetch(ray_ctx *ctx, int64_t num, int32_t *status, int32_t *nsteps, int32_t *nreflect) {
+        if (status) HIPCHK(hipMemcpyAsync(status, st.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+        if (nsteps) HIPCHK(hipMemcpyAsync(nsteps, ns.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+        if (nreflect) HIPCHK(hipMemcpyAsync(nreflect, nr.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+        return RAY_OK;
+    }
+};
+
+int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
+                      const ray_shoot_params *prm, double *m_host, int64_t ld,
+                      int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med)) || (rc = check_params(prm))) return rc;
+    if (!m_host) return fail(RAY_ERR_INVALID, "null m");
+    const int64_t num = (int64_t)(prm->src_end - prm->src_begin) * prm->nd;
+    if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
+    if (num == 0) return RAY_OK;
+    DevBuf dm;
+    RayOutBufs ob_;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    if ((rc = ob_.alloc(num))) return rc;
+    rc = shoot_to_exit_impl(ctx, med, ob, prm, dm.as<double>(), num, ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, 0, 9))) return rc;
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+int ray_shoot_states_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt,
+                         int32_t time_unit, int32_t max_steps, double *m_dev, int64_t num,
+                         int64_t ld, int32_t *status_dev, int32_t *nsteps_dev, int32_t *nreflect_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med))) return rc;
+    if (!m_dev || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad m / num / ld");
+    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    if (time_unit != RAY_TIME_SECONDS && time_unit != RAY_TIME_STEPS) return fail(RAY_ERR_INVALID, "bad time_unit");
+    ShootArgs a{};
+    a.init = 0; a.nd = 1;
+    a.dt = dt; a.time_unit = time_unit; a.max_steps = max_steps;
+    a.m = m_dev; a.num = num; a.ld = ld;
+    a.status = status_dev; a.nsteps = nsteps_dev; a.nreflect = nreflect_dev;
+    return launch_shoot(ctx, med, ob, a);
+}
+
+int ray_shoot_states(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt,
+                     int32_t time_unit, int32_t max_steps, double *m_host, int64_t num, int64_t ld,
+                     int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!m_host || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad m / num / ld");
+    if (num == 0) return RAY_OK;
+    DevBuf dm;
+    RayOutBufs ob_;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    if ((rc = ob_.alloc(num))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
+    rc = ray_shoot_states_dev(ctx, med, ob, dt, time_unit, max_steps, dm.as<double>(), num, num,
+                              ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, 4, 5))) return rc;
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- fixed-time trace -------------------------------------------------------------------------------
+int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
+                             int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
+                             int32_t *status_dev, int32_t *nsteps_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med))) return rc;
+    if (med->kind != kGrid) return fail(RAY_ERR_UNSUPPORTED, "fixed-time trace is defined on gridded media only (Obstacle.jl:275, NonObstacle.jl:141)");
+    if (!m_dev || !X_dev || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
+    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    if (mode != RAY_TRACE_SHORTEN_CEASE && mode != RAY_TRACE_OVERSHOOT) return fail(RAY_ERR_INVALID, "bad mode");
+    if (num == 0) return RAY_OK;
+    TraceArgs a{};
+    a.med = medium_dev(med);
+    a.m = m_dev; a.num = num; a.ld = ld; a.dt = dt; a.mode = mode;
+    a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
+    a.max_steps = 10000000;
+    a.X = X_dev; a.ldx = ldx; a.status = status_dev; a.nsteps = nsteps_dev;
+    a.step_counter = ctx->d_steps;
+    hipEvent_t e0, e1;
+    time_begin(ctx, e0, e1);
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    time_end(ctx, e0, e1);
+    HIPCHK(hipGetLastError());
+    ctx->rays += (uint64_t)num;
+    ctx->launches += 1;
+    return RAY_OK;
+}
+
+int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num,
+                         int64_t ld, double dt, int32_t mode, double *X_host, int64_t ldx,
+                         int32_t *status, int32_t *nsteps)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!m_host || !X_host || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
+    if (num == 0) return RAY_OK;
+    DevBuf dm, dX;
+    RayOutBufs ob_;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
+    if ((rc = ob_.alloc(num))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
+    rc = ray_trace_fixed_time_dev(ctx, med, dm.as<double>(), num, num, dt, mode, dX.as<double>(), num,
+                                  ob_.st.as<int32_t>(), ob_.ns.as<int32_t>());
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- misfit ---------------------------------------------------------------------------------------
+int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
+                   double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!m_dev || !obs_dev || !out_dev || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad misfit arguments");
+    if (mismatch_dev && (reinterpret_cast<uintptr_t>(mismatch_dev) & 15)) return fail(RAY_ERR_INVALID, "mismatch must be 16-byte aligned");
+    hipLaunchKernelGGL(k_misfit_partial, dim3(kMisfitBlocks), dim3(256), 0, ctx->stream, m_dev, obs_dev, num, ld,
+                       perc_thresh, mask_dev, mismatch_dev, ctx->d_partial);
+    hipLaunchKernelGGL(k_misfit_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, out_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64_t num, int64_t ld,
+               double out[2], uint8_t *mask, double perc_thresh, double *mismatch)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!m_host || !obs_host || !out || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad misfit arguments");
+    DevBuf dm, dobs, dout, dmask, dmis;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dobs.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dout.alloc(sizeof(double) * 2));
+    if (mask) HIPCHK(dmask.alloc((size_t)num));
+    if (mismatch) HIPCHK(dmis.alloc(sizeof(double) * 4 * (size_t)num));
+    if (num > 0) {
+        if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 4, 4))) return rc;
+        if ((rc = copy_cols_h2d(ctx, dobs.as<double>(), num, obs_host, ld, num, 4, 4))) return rc;
+    }
+    rc = ray_misfit_dev(ctx, dm.as<double>(), dobs.as<double>(), num, num > 0 ? num : 1, dout.as<double>(),
+                        mask ? dmask.as<uint8_t>() : nullptr, perc_thresh, mismatch ? dmis.as<double>() : nullptr);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask && num) HIPCHK(hipMemcpyAsync(mask, dmask.p, (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+    if (mismatch && num) HIPCHK(hipMemcpyAsync(mismatch, dmis.p, sizeof(double) * 4 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- counters ---------------------------------------------------------------------------------------
+int ray_ctx_enable_timing(ray_ctx *ctx, int on)
+{
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    ctx->timing = on != 0;
+    return RAY_OK;
+}
+
+int ray_get_counters(ray_ctx *ctx, ray_counters *out)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_timing(ctx);
+    unsigned long long s = 0;
+    HIPCHK(hipMemcpy(&s, ctx->d_steps, sizeof(s), hipMemcpyDeviceToHost));
+    out->rays = ctx->rays;
+    out->ray_steps = s;
+    out->launches = ctx->launches;
+    out->kernel_ms = ctx->kernel_ms;
+    return RAY_OK;
+}
+
+int ray_reset_counters(ray_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_timing(ctx);
+    HIPCHK(hipMemset(ctx->d_steps, 0, sizeof(unsigned long long)));
+    ctx->rays = ctx->launches = 0;
+    ctx->kernel_ms = 0;
+    return RAY_OK;
+}
+
+} // extern "C"

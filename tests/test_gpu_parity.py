@@ -1,0 +1,272 @@
+"""GPU parity: the HIP path (through the C ABI, ctypes) against the CPU oracle and the committed
+golden fixtures.  Bars (north_star): <= 1e-10 relative on exit coordinates and traveltime;
+status / step count / reflection count identical.  Where the kernel's arithmetic is the same
+un-fused fp64 sequence as the oracle's (gridded media from explicit states, fixed-time traces,
+tables) the comparison is BIT-EXACT.  The only non-bit-exact inputs are device sin/cos (initial
+direction, analytic media) against the host libm."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def rel_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def assert_rays(m, info, ref_m, ref_st, ref_ns, ref_nr=None, exact=False):
+    assert np.array_equal(info["status"], ref_st)
+    assert np.array_equal(info["nsteps"], ref_ns)
+    if ref_nr is not None:
+        assert np.array_equal(info["nreflect"], ref_nr)
+    if exact:
+        assert np.array_equal(m, ref_m)
+    else:
+        assert rel_err(m[:, 0:8], ref_m[:, 0:8]) <= RTOL
+        assert np.max(np.abs(m[:, 8] - ref_m[:, 8]) / np.maximum(1e-300, np.abs(ref_m[:, 8]))) <= RTOL
+
+
+# ---- a4/a5: tables -------------------------------------------------------------------------
+@pytest.mark.parametrize("fixture", ["tables_n8.npz", "grid_n75_ns8_nd16.npz"])
+def test_tables_golden_bit_exact(ctx, fixture):
+    import ray_amd
+    g = golden(fixture)
+    med = ray_amd.GridMedium(g["c"], float(g["ext"]), ctx)
+    ev, gr, p = med.tables()
+    assert np.array_equal(p, g["p"])
+    assert np.array_equal(ev, g["eval"])
+    assert np.array_equal(gr, g["grad"])
+
+
+@pytest.mark.parametrize("N", [4, 5, 45, 512])
+def test_tables_vs_oracle_bit_exact(ctx, orc, N):
+    import ray_amd
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, N, 1.5)
+    tab = orc.GridTables(c, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ev, gr, p = med.tables()
+    assert np.array_equal(p, tab.p) and np.array_equal(ev, tab.eval) and np.array_equal(gr, tab.grad)
+    # update path: new nodal values, same handle
+    c2 = np.asfortranarray(c * 0.5 + 0.7)
+    med.update(c2)
+    tab2 = orc.GridTables(c2, 1.5)
+    ev, gr, _ = med.tables()
+    assert np.array_equal(ev, tab2.eval) and np.array_equal(gr, tab2.grad)
+
+
+# ---- a6: ScatterRelation ------------------------------------------------------------------------
+def test_scatter_smooth_golden(ctx):
+    import ray_amd
+    g = golden("scatter_smooth_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelation(ray_amd.SinProd(*g["params"]), None, int(g["ns"]), int(g["nd"]),
+                                      float(g["dt"]), (0.0, math.pi), ctx=ctx, info=True)
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
+
+
+def test_scatter_obstacle_golden(ctx):
+    import ray_amd
+    g = golden("scatter_obstacle_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd(*g["params"]), None,
+                                              ray_amd.Circle(float(g["r0"])), None, int(g["ns"]),
+                                              int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert info["nreflect"].sum() > 0
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
+
+
+def test_grid_golden(ctx):
+    import ray_amd
+    g = golden("grid_n75_ns8_nd16.npz")
+    med = ray_amd.GridMedium(g["c"], float(g["ext"]), ctx)
+    m, info = ray_amd.ScatterRelation(med, None, int(g["ns"]), int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"])
+    # explicit states: bit-exact
+    m2 = np.asfortranarray(g["m"].copy())
+    m2[:, 4:] = 0
+    info2 = ray_amd.shoot_states(med, m2, float(g["dt"]), ctx=ctx)
+    assert_rays(m2, info2, g["m"], g["status"], g["nsteps"], exact=True)
+    # a9 / a8 fixed-time traces from the golden states: bit-exact
+    _, s, inf = ray_amd.ScatterForwardOperator(med, g["m"], float(g["ext"]), float(g["trace_dt"]), ctx=ctx, info=True)
+    assert np.array_equal(s[:, 4:8], g["X_shorten"])
+    assert np.array_equal(inf["status"], g["st_shorten"]) and np.array_equal(inf["nsteps"], g["ns_shorten"])
+    assert np.array_equal(s[:, 0:4], g["m"][:, 0:4]) and np.array_equal(s[:, 8], g["m"][:, 8])
+    out, inf = ray_amd.NonReflectionTrace(med, g["m"], float(g["ext"]), float(g["trace_dt"]), ctx=ctx, info=True)
+    assert np.array_equal(out[:, 4:8], g["X_overshoot"])
+    assert np.array_equal(inf["status"], g["st_overshoot"]) and np.array_equal(inf["nsteps"], g["ns_overshoot"])
+    # a11
+    gm = golden("misfit_grid_n75.npz")
+    r = ray_amd.misfit(g["m"], s, 0.2, ctx=ctx)
+    assert abs(r["sum_mismatch2"] - float(gm["sum_mismatch2"])) <= 1e-12 * float(gm["sum_mismatch2"])
+    assert abs(r["sum_target2"] - float(gm["sum_target2"])) <= 1e-12 * float(gm["sum_target2"])
+    assert np.array_equal(r["mask"], gm["mask"])
+
+
+@pytest.mark.parametrize("params,ns,nd,dt", [("SMOOTH_DEMO", 100, 100, 1e-2), ("SMOOTH_DEMO", 7, 333, 5e-3),
+                                             ("OBSTACLE_DEMO", 13, 64, 2e-2)])
+def test_scatter_analytic_vs_oracle(ctx, orc, params, ns, nd, dt):
+    """config 1 (NonObstacleDemo.jl as shipped: 100x100, dt=1e-2) and ragged sizes."""
+    import ray_amd
+    prm = getattr(orc, params)
+    ref, st, nst, nrf = orc.scatter_relation(prm, ns, nd, dt, nthreads=8)
+    m, info = ray_amd.ScatterRelation(ray_amd.SinProd(*prm), None, ns, nd, dt, ctx=ctx, info=True)
+    assert_rays(m, info, ref, st, nst, nrf)
+    assert np.all(st == orc.ST_EXITED)
+
+
+def test_scatter_obstacle_shipped_config(ctx, orc):
+    """config 3 (ObstacleDemo.jl:39-44): 50 x 300 rays, dt = 1e-2, circle r0 = 0.3, t in steps."""
+    import ray_amd
+    ns, nd, dt = 50, 300, 1e-2
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=0.3, time_unit=1, nthreads=8)
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ray_amd.Circle(0.3), None,
+                                              ns, nd, dt, ctx=ctx, info=True)
+    assert nrf.sum() > 1000
+    assert_rays(m, info, ref, st, nst, nrf)
+
+
+def test_theta_block_equals_whole(ctx):
+    """shooting sources [a,b) must give exactly the rows of the full sweep (multi-GPU sharding)."""
+    import ray_amd
+    sp = ray_amd.SinProd.smooth_demo()
+    full = ray_amd.ScatterRelation(sp, None, 12, 40, 1e-2, ctx=ctx)
+    parts = [ray_amd.ScatterRelation(sp, None, 12, 40, 1e-2, ctx=ctx, src_begin=a, src_end=b)
+             for a, b in ((0, 5), (5, 6), (6, 12))]
+    assert np.array_equal(np.vstack(parts), full)
+    empty = ray_amd.ScatterRelation(sp, None, 12, 40, 1e-2, ctx=ctx, src_begin=3, src_end=3)
+    assert empty.shape == (0, 9)
+
+
+# ---- gridded shoot-to-exit at scale: bit-exact against the oracle from explicit states -------------
+@pytest.mark.parametrize("N,ns,nd,dt", [(75, 100, 100, 1e-2), (512, 64, 2048, 1e-2), (45, 50, 300, 5e-2)])
+def test_grid_shoot_vs_oracle(ctx, orc, N, ns, nd, dt):
+    import ray_amd
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+    tab = orc.GridTables(c, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ref, st, nst, _ = orc.scatter_relation(tab, ns, nd, dt, nthreads=16)
+    # (1) library-generated boundary grid: device sin/cos vs libm -> tolerance
+    m, info = ray_amd.ScatterRelation(med, None, ns, nd, dt, ctx=ctx, info=True)
+    assert_rays(m, info, ref, st, nst)
+    # (2) same initial states: bit-exact
+    m2 = np.asfortranarray(ref.copy())
+    m2[:, 4:] = -7.0
+    info2 = ray_amd.shoot_states(med, m2, dt, ctx=ctx)
+    assert_rays(m2, info2, ref, st, nst, exact=True)
+    assert not np.any(st & orc.ST_OOB)
+
+
+def test_grid_obstacle_vs_oracle(ctx, orc):
+    """a7 loop over a gridded medium (composition): bit-exact from explicit states."""
+    import ray_amd
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, 129, 1.5)
+    tab = orc.GridTables(c, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ref, st, nst, nrf = orc.scatter_relation(tab, 16, 256, 1e-2, obstacle_r0=0.3, time_unit=1, nthreads=8)
+    m2 = np.asfortranarray(ref.copy())
+    m2[:, 4:] = 0
+    info = ray_amd.shoot_states(med, m2, 1e-2, ob=ray_amd.Circle(0.3), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
+    assert nrf.sum() > 100
+    assert_rays(m2, info, ref, st, nst, nrf, exact=True)
+
+
+# ---- a8 / a9 at the shipped reconstruction sizes -------------------------------------------------------
+@pytest.mark.parametrize("N,ns,nd", [(75, 100, 100), (45, 50, 300)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_trace_vs_oracle_bit_exact(ctx, orc, N, ns, nd, mode):
+    import ray_amd
+    data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, nthreads=8)     # "measured" m
+    # a perturbed model c0 (as inside the reconstruction loop): rays end away from the boundary
+    c0 = np.asfortranarray(0.85 * orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) + 0.1)
+    tab = orc.GridTables(c0, 1.5)
+    X, st, nst = orc.trace_fixed_time(tab, data, 5e-2, mode, nthreads=8)
+    med = ray_amd.GridMedium(c0, 1.5, ctx)
+    if mode == 0:
+        _, s, inf = ray_amd.ScatterForwardOperator(med, data, 1.5, 5e-2, ctx=ctx, info=True)
+        got = s[:, 4:8]
+    else:
+        out, inf = ray_amd.NonReflectionTrace(med, data, 1.5, 5e-2, ctx=ctx, info=True)
+        got = out[:, 4:8]
+    assert np.array_equal(inf["status"], st) and np.array_equal(inf["nsteps"], nst)
+    assert np.array_equal(got, X)
+
+
+def test_trace_cease_and_oob_flags(ctx, orc):
+    """rays that leave 1+2h are ceased (a9) / run off the grid and are clamped + flagged (a8)."""
+    import ray_amd
+    N = 45
+    c0 = np.asfortranarray(np.full((N, N), 1.0))
+    tab = orc.GridTables(c0, 1.5)
+    data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, 10, 50, 1e-2, nthreads=4)
+    data[:, 8] *= 3.0                                   # far too long: rays fly out of the disk
+    med = ray_amd.GridMedium(c0, 1.5, ctx)
+    for mode in (0, 1):
+        X, st, nst = orc.trace_fixed_time(tab, data, 5e-2, mode, nthreads=4)
+        Xg, inf = ray_amd._trace(med, data, 1.5, 5e-2, mode, ctx, True)
+        assert np.array_equal(inf["status"], st) and np.array_equal(inf["nsteps"], nst)
+        assert np.array_equal(Xg, X)
+        if mode == 0:
+            assert np.any(st & orc.ST_CEASED)
+        else:
+            assert np.any(st & orc.ST_OOB)
+
+
+# ---- a11 -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("num", [0, 1, 255, 15000, 300001])
+def test_misfit_vs_oracle(ctx, orc, num):
+    import ray_amd
+    rng = np.random.default_rng(1234 + num)
+    m = np.asfortranarray(rng.standard_normal((num, 9)))
+    obs = np.asfortranarray(m + 0.15 * rng.standard_normal((num, 9)) * rng.random((num, 1)))
+    mism, out, mask = orc.misfit(m, obs, 0.2)
+    r = ray_amd.misfit(m, obs, 0.2, ctx=ctx)
+    assert np.array_equal(r["mismatch"], mism)
+    assert np.array_equal(r["mask"], mask)
+    for got, ref in ((r["sum_mismatch2"], out[0]), (r["sum_target2"], out[1])):
+        assert abs(got - ref) <= 1e-12 * max(abs(ref), 1e-300)
+
+
+# ---- size-independent properties at the BASELINE config-2 size (2048 x 2048 rays, 512^2 grid) --------
+def test_full_size_properties(ctx, orc):
+    import ray_amd
+    N, ns, nd, dt = 512, 2048, 2048, 1e-2
+    med1 = ray_amd.GridMedium(np.ones((N, N), order="F"), 1.5, ctx)
+    # K1/K6 (c == 1): straight chords; exit angle = s + 2 phi, p unchanged, t = 2 sin(phi)
+    ctx.reset_counters()
+    m, info = ray_amd.ScatterRelation(med1, None, ns, nd, dt, ctx=ctx, info=True)
+    cnt = ctx.counters()
+    assert cnt["rays"] == ns * nd and cnt["ray_steps"] == int(info["nsteps"].astype(np.int64).sum())
+    assert np.all(info["status"] == ray_amd.ST_EXITED)
+    src = np.repeat(orc.linspace(0, 2 * math.pi, ns + 1)[:ns], nd)
+    phi = np.tile(orc.linspace(0, math.pi, nd + 2)[1:nd + 1], ns)
+    assert np.max(np.abs(m[:, 8] - 2 * np.sin(phi))) < 1e-12
+    assert np.max(np.abs(m[:, 4] - np.cos(src + 2 * phi))) < 1e-12
+    assert np.max(np.abs(m[:, 5] - np.sin(src + 2 * phi))) < 1e-12
+    assert np.max(np.abs(m[:, 6:8] - m[:, 2:4])) < 1e-13
+    assert np.max(np.abs(np.sqrt(m[:, 4] * m[:, 4] + m[:, 5] * m[:, 5]) - 1)) <= 1e-15
+    # K4 time reversal on the smooth medium: re-shoot from (x1, -p1) returns (x0, -p0) to O(dt^2)
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    m, info = ray_amd.ScatterRelation(med, None, ns, nd, dt, ctx=ctx, info=True)
+    assert np.all(info["status"] == ray_amd.ST_EXITED)
+    # K3: c |p| = 1 is conserved; at the exit point c is the gridded value
+    back = np.zeros_like(m, order="F")
+    back[:, 0:2] = m[:, 4:6]
+    back[:, 2:4] = -m[:, 6:8]
+    inf2 = ray_amd.shoot_states(med, back, dt, ctx=ctx)
+    ok = (info["nsteps"] > 3)                      # the very short grazing chords exit in 1-2 steps
+    assert np.max(np.abs(back[ok, 4:6] - m[ok, 0:2])) < 5e-3
+    assert np.max(np.abs(back[ok, 8] - m[ok, 8])) < 5e-3
+    assert np.all(inf2["status"] & ray_amd.ST_EXITED)
+    # sub-sample against the oracle, bit-exact from the same states
+    idx = np.arange(0, ns * nd, 4099)
+    sub = np.asfortranarray(m[idx].copy())
+    ref = np.asfortranarray(sub.copy())
+    tab = orc.GridTables(c, 1.5)
+    st, nst, _ = orc.shoot(tab, ref, dt, nthreads=16)
+    assert np.array_equal(ref, sub)
+    assert np.array_equal(info["nsteps"][idx], nst) and np.array_equal(info["status"][idx], st)
