@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libray_amd.so")
+LIB_PATH = os.environ.get("RAY_AMD_LIB") or os.path.join(_HERE, "libray_amd.so")
 
 RAY_OK = 0
 ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED = 0x01, 0x02, 0x04, 0x08, 0x10

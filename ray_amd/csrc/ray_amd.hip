@@ -85,11 +85,36 @@ __device__ __forceinline__ double ob_val(double r0, double x, double y) { return
 // wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
 // The exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
 // wavefront has left the disk and is then run by all lanes at once.
+#ifndef RAY_LB_WAVES
+#define RAY_LB_WAVES 1
+#endif
+#ifndef RAY_BLOCK
+#define RAY_BLOCK 256
+#endif
+
+// node coordinates p[] for the kernels: read from HBM/L1, or (RAY_P_LDS) staged once per
+// workgroup into LDS so the two coordinate look-ups of every right-hand side leave the
+// vector-memory path.
+template <int MED>
+__device__ __forceinline__ const double *stage_nodes(const MediumDev &med)
+{
+#ifdef RAY_P_LDS
+    extern __shared__ double p_lds[];
+    if (MED == kGrid) {
+        for (int k = threadIdx.x; k < med.g.N; k += blockDim.x) p_lds[k] = med.g.p[k];
+        __syncthreads();
+        return p_lds;
+    }
+#endif
+    return med.g.p;
+}
+
 template <int MED, int OB>
-__global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, RAY_LB_WAVES) void k_shoot(const ShootArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < a.num;
+    const double *pt = stage_nodes<MED>(a.med);
     double X[4] = {0, 0, 0, 0}, P[4] = {0, 0, 0, 0};
     int st = 0, oob = 0;
     if (valid) {
@@ -100,7 +125,7 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
             const double theta = a.src[il] + a.half_pi + a.direct[j];
             double sn, cs;
             sincos(theta, &sn, &cs);
-            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, sx, sy, oob)
+            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, pt, sx, sy, oob)
                                              : speed_sinprod(a.med.sp, sx, sy);
             X[0] = sx; X[1] = sy; X[2] = cs / c0; X[3] = sn / c0;
 #pragma unroll
@@ -118,7 +143,7 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
         if (OB == kObCircle) { if (ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
 #pragma unroll
         for (int k = 0; k < 4; ++k) P[k] = X[k];
-        rk4_kdt<MED>(a.med, X, dt, oob);
+        rk4_kdt<MED>(a.med, pt, X, dt, oob);
         ++steps;
         t = a.time_unit ? t + 1 : t + dt;
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
@@ -205,10 +230,11 @@ struct TraceArgs {
 
 // a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
 // NonObstacle.jl:146-157,161-164,171,177-181,185).
-__global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
+__global__ __launch_bounds__(256, RAY_LB_WAVES) void k_trace(const TraceArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < a.num;
+    const double *pt = stage_nodes<kGrid>(a.med);
     double X[4] = {0, 0, 0, 0};
     double T = 0;
     if (valid) {
@@ -222,7 +248,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         if (steps >= a.max_steps) { st |= kStStepCap; break; }
         if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;
         t = t + dt;
-        rk4_k<kGrid>(a.med, X, dt, oob);
+        rk4_k<kGrid>(a.med, pt, X, dt, oob);
         ++steps;
         if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
             // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
@@ -640,6 +666,16 @@ static MediumDev medium_dev(const ray_medium *m)
     return d;
 }
 
+static size_t nodes_lds_bytes(const ray_medium *med)
+{
+#ifdef RAY_P_LDS
+    return med->kind == kGrid ? sizeof(double) * (size_t)med->N : 0;
+#else
+    (void)med;
+    return 0;
+#endif
+}
+
 // ---- shooting -----------------------------------------------------------------------------------
 static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, ShootArgs &a)
 {
@@ -652,12 +688,13 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
-    const dim3 grid((unsigned)((a.num + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((a.num + RAY_BLOCK - 1) / RAY_BLOCK)), block(RAY_BLOCK);
+    const size_t lds = nodes_lds_bytes(med);
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
     if (med->kind == kGrid) {
-        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kGrid, kObNone>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle>), grid, block, 0, ctx->stream, a);
+        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kGrid, kObNone>), grid, block, lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle>), grid, block, lds, ctx->stream, a);
     } else {
         if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone>), grid, block, 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle>), grid, block, 0, ctx->stream, a);
@@ -832,7 +869,7 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
     a.step_counter = ctx->d_steps;
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + RAY_BLOCK - 1) / RAY_BLOCK)), dim3(RAY_BLOCK), nodes_lds_bytes(med), ctx->stream, a);
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)num;

@@ -58,14 +58,14 @@ __device__ __forceinline__ int cell0(double x, const GridDev &g, int &oob)
 }
 
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
-__device__ __forceinline__ void rhs_grid(const GridDev &g, const double X[4], double H[4], int &oob)
+__device__ __forceinline__ void rhs_grid(const GridDev &g, const double *pt, const double X[4], double H[4], int &oob)
 {
     const int i = cell0(X[0], g, oob);
     const int j = cell0(X[1], g, oob);
     const double2 *r = reinterpret_cast<const double2 *>(g.rec) +
                        ((size_t)i + (size_t)j * (size_t)(g.N - 1)) * 6;
     const double2 e01 = r[0], e23 = r[1], a01 = r[2], a23 = r[3], b01 = r[4], b23 = r[5];
-    const double dx = X[0] - g.p[i], dy = X[1] - g.p[j];
+    const double dx = X[0] - pt[i], dy = X[1] - pt[j];
     const double dxdy = dx * dy;
     const double tau = X[2] * X[2] + X[3] * X[3];
     const double c = ((e01.x + dx * e01.y) + dy * e23.x) + dxdy * e23.y;
@@ -79,14 +79,14 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const double X[4], do
 }
 
 // z' * eval[I,J,:] alone (c at the sensor for the initial slowness)  NonObstacle.jl:39,62
-__device__ __forceinline__ double speed_grid(const GridDev &g, double x, double y, int &oob)
+__device__ __forceinline__ double speed_grid(const GridDev &g, const double *pt, double x, double y, int &oob)
 {
     const int i = cell0(x, g, oob);
     const int j = cell0(y, g, oob);
     const double2 *r = reinterpret_cast<const double2 *>(g.rec) +
                        ((size_t)i + (size_t)j * (size_t)(g.N - 1)) * 6;
     const double2 e01 = r[0], e23 = r[1];
-    const double dx = x - g.p[i], dy = y - g.p[j];
+    const double dx = x - pt[i], dy = y - pt[j];
     return ((e01.x + dx * e01.y) + dy * e23.x) + (dx * dy) * e23.y;
 }
 
@@ -117,46 +117,46 @@ struct MediumDev {
 };
 
 template <int MED>
-__device__ __forceinline__ void rhs(const MediumDev &m, const double X[4], double H[4], int &oob)
+__device__ __forceinline__ void rhs(const MediumDev &m, const double *pt, const double X[4], double H[4], int &oob)
 {
-    if (MED == kGrid) rhs_grid(m.g, X, H, oob);
+    if (MED == kGrid) rhs_grid(m.g, pt, X, H, oob);
     else rhs_sinprod(m.sp, X, H);
 }
 
 // classical RK4, a6/a7 form: k = H*dt; X + k1/2; ...; /6.0       NonObstacle.jl:72-76
 template <int MED>
-__device__ __forceinline__ void rk4_kdt(const MediumDev &m, double X[4], double dt, int &oob)
+__device__ __forceinline__ void rk4_kdt(const MediumDev &m, const double *pt, double X[4], double dt, int &oob)
 {
     double H[4], Y[4], acc[4];
-    rhs<MED>(m, X, H, oob);
+    rhs<MED>(m, pt, X, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = X[k] + kk * 0.5; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = acc[k] + 2 * kk; Y[k] = X[k] + kk * 0.5; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = acc[k] + 2 * kk; Y[k] = X[k] + kk; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; X[k] = X[k] + div6(acc[k] + kk); }
 }
 
 // a8/a9 form: k = H; X + k/2*dt; X += (k1+2k2+2k3+k4)*dt/6.0     NonObstacle.jl:161-164,171
 template <int MED>
-__device__ __forceinline__ void rk4_k(const MediumDev &m, double X[4], double dt, int &oob)
+__device__ __forceinline__ void rk4_k(const MediumDev &m, const double *pt, double X[4], double dt, int &oob)
 {
     double H[4], Y[4], acc[4];
-    rhs<MED>(m, X, H, oob);
+    rhs<MED>(m, pt, X, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + (H[k] * 0.5) * dt; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { acc[k] = acc[k] + 2 * H[k]; Y[k] = X[k] + (H[k] * 0.5) * dt; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { acc[k] = acc[k] + 2 * H[k]; Y[k] = X[k] + H[k] * dt; }
-    rhs<MED>(m, Y, H, oob);
+    rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
     for (int k = 0; k < 4; ++k) X[k] = X[k] + div6((acc[k] + H[k]) * dt);
 }
