@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -64,6 +65,8 @@ struct ShootArgs {
     // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
     int init;
     int nd;
+    int nsrc;               // sources in this call (src_end - src_begin)
+    int ngroup;             // source groups per direction chunk = ceil(nsrc / waves per block)
     const double *src;      // source[i]            (local index i - src_begin)
     const double *src_cos;  // cos(source[i])  host libm
     const double *src_sin;  // sin(source[i])
@@ -85,47 +88,61 @@ __device__ __forceinline__ double ob_val(double r0, double x, double y) { return
 // wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
 // The exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
 // wavefront has left the disk and is then run by all lanes at once.
-#ifndef RAY_LB_WAVES
-#define RAY_LB_WAVES 1
-#endif
-#ifndef RAY_BLOCK
-#define RAY_BLOCK 256
-#endif
-
-// node coordinates p[] for the kernels: read from HBM/L1, or (RAY_P_LDS) staged once per
-// workgroup into LDS so the two coordinate look-ups of every right-hand side leave the
-// vector-memory path.
-template <int MED>
-__device__ __forceinline__ const double *stage_nodes(const MediumDev &med)
+__device__ __forceinline__ void lerp4(double E[4], const double P[4], const double X[4], double mid)
 {
-#ifdef RAY_P_LDS
-    extern __shared__ double p_lds[];
-    if (MED == kGrid) {
-        for (int k = threadIdx.x; k < med.g.N; k += blockDim.x) p_lds[k] = med.g.p[k];
-        __syncthreads();
-        return p_lds;
-    }
-#endif
-    return med.g.p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
 }
 
+// a6 / a7: ScatterRelation / ScatterRelationObstacle per-ray loop.
+// NonObstacle.jl:67-97; Obstacle.jl:23-95.  Lanes = consecutive directions of one source, so a
+// wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
+//  - the RK4 step is executed by ALL 64 lanes while any lane of the wavefront is alive (finished
+//    lanes integrate their frozen state and discard the result): the gridded right-hand side
+//    fetches cell records wave-cooperatively (ray_device.h) and needs the wave converged;
+//  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
+//    wavefront has left the disk and is then run by all lanes at once.
 template <int MED, int OB>
-__global__ __launch_bounds__(256, RAY_LB_WAVES) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = r < a.num;
-    const double *pt = stage_nodes<MED>(a.med);
-    double X[4] = {0, 0, 0, 0}, P[4] = {0, 0, 0, 0};
+    // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
+    // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
+    // `waves per block` adjacent sources (equal ray lengths -> the waves retire together; adjacent
+    // fans -> shared cache lines).  Chunks are dispatched longest-first -- chord length ~ 2 sin(phi)
+    // peaks at the middle chunk -- which is the GPU form of the reference's sort-by-traveltime
+    // balancer (NonObstacle.jl:223-233): the short grazing rays fill the tail of the launch.
+    // Within a chunk, groups are dealt so that each XCD (blockIdx % 8) sweeps a contiguous arc of
+    // sources and keeps that arc's cells in its own L2.
+    int64_t r;
+    bool valid;
+    int64_t il = 0;
+    int j = 0;
+    if (a.init) {
+        const int nchunk = (a.nd + 63) >> 6;
+        const int rank = (int)(blockIdx.x / (unsigned)a.ngroup);
+        int gi = (int)(blockIdx.x - (unsigned)rank * (unsigned)a.ngroup);
+        if ((a.ngroup & 7) == 0) gi = (gi & 7) * (a.ngroup >> 3) + (gi >> 3);
+        const int mid = nchunk >> 1, hh = (rank + 1) >> 1;
+        const int chunk = (rank & 1) ? mid - hh : mid + hh;
+        il = (int64_t)gi * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        j = chunk * 64 + (int)(threadIdx.x & 63);
+        valid = il < a.nsrc && j < a.nd;
+        r = il * a.nd + j;
+    } else {
+        r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        valid = r < a.num;
+    }
+    GridAcc acc{};
+    if (MED == kGrid) acc = grid_acc_setup(a.med.g);
+    double X[4] = {0, 0, 1, 0};                             // harmless state for padding lanes
     int st = 0, oob = 0;
     if (valid) {
         if (a.init) {
-            const int64_t il = r / a.nd;
-            const int j = (int)(r - il * a.nd);
             const double sx = a.src_cos[il], sy = a.src_sin[il];
             const double theta = a.src[il] + a.half_pi + a.direct[j];
             double sn, cs;
             sincos(theta, &sn, &cs);
-            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, pt, sx, sy, oob)
+            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, lds_nodes(), sx, sy, oob)
                                              : speed_sinprod(a.med.sp, sx, sy);
             X[0] = sx; X[1] = sy; X[2] = cs / c0; X[3] = sn / c0;
 #pragma unroll
@@ -134,67 +151,76 @@ __global__ __launch_bounds__(256, RAY_LB_WAVES) void k_shoot(const ShootArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
         }
+        if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;    // NaN position: see cell0()
     }
     double t = 0;
     int steps = 0, nref = 0, rfl = 0;
     bool active = valid;
     const double dt = a.dt;
-    while (active) {
-        if (OB == kObCircle) { if (ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
+    while (__any(active)) {
+        if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
+        double Xn[4];
+        int o = 0;
+        rk4_kdt<MED>(a.med, acc, X, Xn, dt, o);
+        if (active) {
+            double P[4];                       // state before the step (NonObstacle.jl:71 `prev`)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) P[k] = X[k];
-        rk4_kdt<MED>(a.med, pt, X, dt, oob);
-        ++steps;
-        t = a.time_unit ? t + 1 : t + dt;
-        // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
-        const double s = X[0] * X[0] + X[1] * X[1];
-        if (s >= 1.0) { st |= kStExited; active = false; }
-        else {
-            if (OB == kObCircle) {
-                if (ob_val(a.ob_r0, X[0], X[1]) <= 0 && rfl == 0) {              // Obstacle.jl:69-91
-                    double lo = 0, hi = 1, mid = 0.5, E[4], e;
-                    int it = 0;
-                    rfl = 1;
+            for (int k = 0; k < 4; ++k) { P[k] = X[k]; X[k] = Xn[k]; }
+            ++steps;
+            t = a.time_unit ? t + 1 : t + dt;
+            // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
+            const double s = X[0] * X[0] + X[1] * X[1];
+            oob |= o | !(s == s);
+            if (s >= 1.0) {
+                // parked in the output row until the deferred bisection below picks it up
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
-                    e = ob_val(a.ob_r0, E[0], E[1]);
-                    while (__builtin_fabs(e) > 1e-15) {
-                        if (++it > kBisectCap) { st |= kStBisectCap; break; }
-                        if (e > 0) lo = mid; else hi = mid;
-                        mid = (lo + hi) * 0.5;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+                for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = P[k];
+                st |= kStExited; active = false;
+            } else {
+                if (OB == kObCircle) {
+                    if (ob_val(a.ob_r0, X[0], X[1]) <= 0 && rfl == 0) {          // Obstacle.jl:69-91
+                        double lo = 0, hi = 1, mid = 0.5, E[4], e;
+                        int it = 0;
+                        rfl = 1;
+                        lerp4(E, P, X, mid);
                         e = ob_val(a.ob_r0, E[0], E[1]);
+                        while (__builtin_fabs(e) > 1e-15) {
+                            if (++it > kBisectCap) { st |= kStBisectCap; break; }
+                            if (e > 0) lo = mid; else hi = mid;
+                            mid = (lo + hi) * 0.5;
+                            lerp4(E, P, X, mid);
+                            e = ob_val(a.ob_r0, E[0], E[1]);
+                        }
+                        // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
+                        const double rr = norm2(E[0], E[1]);
+                        double nx = E[0] / rr, ny = E[1] / rr;
+                        const double nn = norm2(nx, ny);
+                        nx = nx / nn; ny = ny / nn;
+                        const double a0 = 2 * nx, a1 = 2 * ny;
+                        const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
+                        const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
+                        X[0] = E[0]; X[1] = E[1];
+                        X[2] = m11 * E[2] + m12 * E[3];
+                        X[3] = m21 * E[2] + m22 * E[3];
+                        ++nref;
                     }
-                    // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
-                    const double rr = norm2(E[0], E[1]);
-                    double nx = E[0] / rr, ny = E[1] / rr;
-                    const double nn = norm2(nx, ny);
-                    nx = nx / nn; ny = ny / nn;
-                    const double a0 = 2 * nx, a1 = 2 * ny;
-                    const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
-                    const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
-                    X[0] = E[0]; X[1] = E[1];
-                    X[2] = m11 * E[2] + m12 * E[3];
-                    X[3] = m21 * E[2] + m22 * E[3];
-                    ++nref;
                 }
+                if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
             }
-            if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
         }
     }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
-        double lo = 0, hi = 1, mid = 0.5, E[4], e;
+        double lo = 0, hi = 1, mid = 0.5, E[4], e, P[4];
         int it = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+        for (int k = 0; k < 4; ++k) P[k] = a.m[r + (4 + k) * a.ld];
+        lerp4(E, P, X, mid);
         e = norm2(E[0], E[1]) - 1;
         while (__builtin_fabs(e) > 1e-15) {
             if (++it > kBisectCap) { st |= kStBisectCap; break; }
             if (e > 0) hi = mid; else lo = mid;
             mid = (lo + hi) * 0.5;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) E[k] = (1 - mid) * P[k] + mid * X[k];
+            lerp4(E, P, X, mid);
             e = norm2(E[0], E[1]) - 1;
         }
         t = a.time_unit ? t - (1 - mid) : t - (1 - mid) * dt;
@@ -230,36 +256,50 @@ struct TraceArgs {
 
 // a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
 // NonObstacle.jl:146-157,161-164,171,177-181,185).
-__global__ __launch_bounds__(256, RAY_LB_WAVES) void k_trace(const TraceArgs a)
+__global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < a.num;
-    const double *pt = stage_nodes<kGrid>(a.med);
-    double X[4] = {0, 0, 0, 0};
+    const GridAcc acc = grid_acc_setup(a.med.g);
+    double X[4] = {0, 0, 1, 0};
     double T = 0;
+    int steps = 0, st = 0, oob = 0;
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
         T = a.m[r + 8 * a.ld];
+        if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;
     }
     double t = 0, dt = a.dt;
-    int steps = 0, st = 0, oob = 0;
-    while (valid && t < T) {
-        if (steps >= a.max_steps) { st |= kStStepCap; break; }
-        if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;
-        t = t + dt;
-        rk4_k<kGrid>(a.med, pt, X, dt, oob);
-        ++steps;
-        if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
-            // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
-            // threshold; outside it the squared comparison decides with certainty.
+    bool active = valid && t < T;
+    while (__any(active)) {                     // all lanes step together (cooperative fetch)
+        if (active) {
+            if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
+            else {
+                if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;
+                t = t + dt;
+            }
+        }
+        double Xn[4];
+        int o = 0;
+        rk4_k<kGrid>(a.med, acc, X, Xn, dt, o);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X[k] = Xn[k];
+            ++steps;
             const double s = X[0] * X[0] + X[1] * X[1];
-            const double c2 = a.cease_r * a.cease_r;
-            bool out;
-            if (s > c2 * 1.0000000001) out = true;
-            else if (s < c2 * 0.9999999999) out = false;
-            else out = __builtin_sqrt(s) > a.cease_r;
-            if (out) { t = t + (T - t); st |= kStCeased; }
+            oob |= o | !(s == s);
+            if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
+                // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
+                // threshold; outside it the squared comparison decides with certainty.
+                const double c2 = a.cease_r * a.cease_r;
+                bool out;
+                if (s > c2 * 1.0000000001) out = true;
+                else if (s < c2 * 0.9999999999) out = false;
+                else out = __builtin_sqrt(s) > a.cease_r;
+                if (out) { t = t + (T - t); st |= kStCeased; }
+            }
+            active = t < T;
         }
     }
     if (oob) st |= kStOob;
@@ -565,6 +605,7 @@ int ray_medium_create_grid(ray_ctx *ctx, const double *c_host, int N, double ext
     int rc = use(ctx);
     if (rc) return rc;
     if (!c_host || N < 4 || !(ext > 0)) return fail(RAY_ERR_INVALID, "grid medium needs c, N >= 4, ext > 0");
+    if (N > 4096) return fail(RAY_ERR_UNSUPPORTED, "grid medium supports N <= 4096 (24-bit cell ids, LDS node table)");
     ray_medium *m = new ray_medium;
     m->ctx = ctx; m->kind = kGrid; m->N = N; m->ext = ext;
     m->p.resize(N);
@@ -666,14 +707,19 @@ static MediumDev medium_dev(const ray_medium *m)
     return d;
 }
 
+// workgroup size of the integration kernels (multiple of 64); RAY_BLOCK overrides for experiments
+static int block_threads()
+{
+    static int b = [] {
+        const char *e = getenv("RAY_BLOCK");
+        int v = e ? atoi(e) : 256;
+        return (v == 64 || v == 128 || v == 256) ? v : 256;
+    }();
+    return b;
+}
 static size_t nodes_lds_bytes(const ray_medium *med)
 {
-#ifdef RAY_P_LDS
-    return med->kind == kGrid ? sizeof(double) * (size_t)med->N : 0;
-#else
-    (void)med;
-    return 0;
-#endif
+    return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads()) : 0;
 }
 
 // ---- shooting -----------------------------------------------------------------------------------
@@ -688,8 +734,15 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
-    const dim3 grid((unsigned)((a.num + RAY_BLOCK - 1) / RAY_BLOCK)), block(RAY_BLOCK);
+    const int bt = block_threads(), wpb = bt / 64;
+    unsigned nblk;
+    if (a.init) {
+        a.ngroup = (a.nsrc + wpb - 1) / wpb;
+        nblk = (unsigned)(((a.nd + 63) / 64) * a.ngroup);
+    } else nblk = (unsigned)((a.num + bt - 1) / bt);
+    const dim3 grid(nblk), block(bt);
     const size_t lds = nodes_lds_bytes(med);
+    if (lds > 160 * 1024) return fail(RAY_ERR_UNSUPPORTED, "grid too large for the LDS node table");
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
     if (med->kind == kGrid) {
@@ -734,7 +787,7 @@ static int shoot_to_exit_impl(ray_ctx *ctx, const ray_medium *med, const ray_obs
     int rc = init_tables(ctx, prm, &tab);
     if (rc) return rc;
     ShootArgs a{};
-    a.init = 1; a.nd = prm->nd;
+    a.init = 1; a.nd = prm->nd; a.nsrc = prm->src_end - prm->src_begin;
     a.src = tab->src.as<double>(); a.src_cos = tab->cs.as<double>(); a.src_sin = tab->sn.as<double>();
     a.direct = tab->dir.as<double>();
     a.half_pi = M_PI * 0.5;
@@ -869,7 +922,7 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
     a.step_counter = ctx->d_steps;
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + RAY_BLOCK - 1) / RAY_BLOCK)), dim3(RAY_BLOCK), nodes_lds_bytes(med), ctx->stream, a);
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + block_threads() - 1) / block_threads())), dim3(block_threads()), nodes_lds_bytes(med), ctx->stream, a);
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)num;

@@ -47,30 +47,143 @@ __device__ __forceinline__ double div6(double a)
     return div_rn(a, 6.0, 0.16666666666666666);
 }
 
+// ---- per-thread access context for the gridded medium -----------------------------------------
+// LDS carve-up per workgroup (dynamic shared memory, see grid_lds_bytes()):
+//   [ p[0..N) node coordinates | per wave: 64 x 96-byte record slots | per wave: 64 cell ids ]
+// The node table leaves the vector-memory path entirely; the record slots are the landing zone of
+// the wave-cooperative record fetch below.
+constexpr int kRunSlots = 64;                       // record slots per wave: one per lane, never overflows
+constexpr int kPasses = (kRunSlots * 6 + 63) / 64;  // global_load_lds passes to fill them all (5)
+constexpr int kWaveLdsBytes = kRunSlots * 96 + kRunSlots * 4;
+
+struct GridAcc {
+    unsigned wrec;           // LDS byte offset of this wave's record slots
+    unsigned wcells;         // LDS byte offset of this wave's cell-id slots
+    unsigned lane;
+};
+
+__host__ __device__ inline size_t grid_lds_bytes(int N, int block)
+{
+    return (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)(block / 64) * kWaveLdsBytes;
+}
+
+extern __shared__ __attribute__((aligned(16))) char ray_smem[];   // [ p | record slots | cell ids ]
+
+__device__ __forceinline__ const double *lds_nodes() { return reinterpret_cast<const double *>(ray_smem); }
+
+__device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
+{
+    GridAcc a;
+    double *p_lds = reinterpret_cast<double *>(ray_smem);
+    for (int k = threadIdx.x; k < g.N; k += blockDim.x) p_lds[k] = g.p[k];
+    const unsigned poff = ((unsigned)g.N * 8u + 15u) & ~15u;
+    const unsigned wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    a.wrec = poff + wave * (kRunSlots * 96);
+    a.wcells = poff + nw * (kRunSlots * 96) + wave * (kRunSlots * 4);
+    a.lane = threadIdx.x & 63;
+    // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
+    if (a.lane < (unsigned)kRunSlots) *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
+    __syncthreads();
+    return a;
+}
+
 // I-1 for I = Int64(floor((x - p[1])/h)) + 1, clamped to the cells whose grad entry exists
-// (reference: undefined behaviour outside; here flagged)           NonObstacle.jl:33-34
+// (reference: undefined behaviour outside; here flagged).            NonObstacle.jl:33-34
+// v_cvt_i32_f64 saturates and maps NaN to 0; a NaN position is flagged by the callers' own
+// per-step check, so the flag word equals the CPU restatement's in every case.
 __device__ __forceinline__ int cell0(double x, const GridDev &g, int &oob)
 {
-    double q = __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
-    double qc = __builtin_fmin(__builtin_fmax(q, 0.0), (double)(g.N - 3));
-    oob |= (qc != q);
-    return (int)qc;
+    const double q = __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
+    int iraw;                                    // saturating; (int)q would be UB out of range
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
+    int i;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
+    oob |= (i != iraw);
+    return i;
+}
+
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+// Wave-cooperative fetch of the 96-byte cell records (ALL 64 lanes must call this together).
+// Lanes are consecutive directions of one source, so along the wavefront the cell index changes
+// only every few lanes: a lane is a "leader" when its cell differs from its left neighbour's.
+// Each run of equal cells is fetched ONCE, as 16-byte pieces by global_load_lds (in pass t lane l
+// loads piece (64t+l)%6 of run (64t+l)/6 straight into LDS), then every lane reads its run's record
+// back with 6 ds_read_b128.  Per right-hand side this moves ~17 x 96 B through the L1 instead of
+// 64 x 96 B; the L1 tag rate, not HBM or the VALU, bounds the per-lane gather form (profiles/).
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c)   // v_mad_u32_u24
+{
+    return __umul24(a, b) + c;
+}
+
+__device__ __forceinline__ void load_piece(const char *rec, const GridAcc &a, unsigned lane, int t, unsigned npiece)
+{
+    const unsigned q = t * 64u + lane, run = (q * 171u) >> 10;               // run = q / 6 for q < 505
+    const unsigned c = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run * 4u);
+    if (q < npiece)
+        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, (q - run * 6u) * 16u)),
+                                         (lptr_t)(ray_smem + a.wrec + t * 1024u), 16, 0, 0);
+}
+
+__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int cid, double2 out[6])
+{
+    // left neighbour's cell (wave_shr:1; lane 0 keeps ~cid, i.e. is always a leader)
+    const int left = __builtin_amdgcn_update_dpp(~cid, cid, 0x138, 0xf, 0xf, false);
+    const bool leader = left != cid;
+    const unsigned long long mask = __ballot(leader);
+    const unsigned npiece = 6u * (unsigned)__builtin_popcountll(mask);       // wave-uniform, >= 6
+    const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const unsigned rank = before + (leader ? 1u : 0u) - 1u;                  // run index of this lane
+    if (leader) *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
+    const char *rec = reinterpret_cast<const char *>(g.rec);
+    // passes 0 and 1 (<= 21 runs, the common case): both cell-id reads first, then both DMA loads
+    const unsigned q1 = 64u + a.lane, run0 = (a.lane * 171u) >> 10, run1 = (q1 * 171u) >> 10;
+    unsigned c0 = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run0 * 4u);
+    unsigned c1 = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run1 * 4u);
+    asm volatile("" : "+v"(c0), "+v"(c1));                                   // keep the reads ahead of the masks
+    if (a.lane < npiece)
+        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c0, 96u, (a.lane - run0 * 6u) * 16u)),
+                                         (lptr_t)(ray_smem + a.wrec), 16, 0, 0);
+    if (q1 < npiece)
+        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c1, 96u, (q1 - run1 * 6u) * 16u)),
+                                         (lptr_t)(ray_smem + a.wrec + 1024u), 16, 0, 0);
+    if (npiece > 128u) {                                                     // wide fans: up to 4 more passes
+        unsigned lane = a.lane;
+        asm volatile("" : "+v"(lane));                                       // recompute the roles here, do not
+#pragma unroll                                                               // hold them in registers all kernel
+        for (int t = 2; t < kPasses; ++t)
+            if (npiece > 64u * t) load_piece(rec, a, lane, t, npiece);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = r[k];
 }
 
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
-__device__ __forceinline__ void rhs_grid(const GridDev &g, const double *pt, const double X[4], double H[4], int &oob)
+// COOP: all 64 lanes are converged here -> wave-cooperative record fetch; otherwise per-lane loads.
+template <bool COOP>
+__device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], int &oob)
 {
     const int i = cell0(X[0], g, oob);
     const int j = cell0(X[1], g, oob);
-    const double2 *r = reinterpret_cast<const double2 *>(g.rec) +
-                       ((size_t)i + (size_t)j * (size_t)(g.N - 1)) * 6;
-    const double2 e01 = r[0], e23 = r[1], a01 = r[2], a23 = r[3], b01 = r[4], b23 = r[5];
-    const double dx = X[0] - pt[i], dy = X[1] - pt[j];
+    const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
+    const double *pt = lds_nodes();
+    const double pi_ = pt[i], pj_ = pt[j];
+    double2 r[6];
+    if (COOP) fetch_records(g, a, cid, r);
+    else {
+        const double2 *src = reinterpret_cast<const double2 *>(g.rec) + (size_t)cid * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = src[k];
+    }
+    const double dx = X[0] - pi_, dy = X[1] - pj_;
     const double dxdy = dx * dy;
     const double tau = X[2] * X[2] + X[3] * X[3];
-    const double c = ((e01.x + dx * e01.y) + dy * e23.x) + dxdy * e23.y;
-    const double gcX = ((a01.x + dx * a01.y) + dy * a23.x) + dxdy * a23.y;
-    const double gcY = ((b01.x + dx * b01.y) + dy * b23.x) + dxdy * b23.y;
+    const double c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
+    const double gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
+    const double gcY = ((r[4].x + dx * r[4].y) + dy * r[5].x) + dxdy * r[5].y;
     const double c2 = c * c;
     H[0] = c2 * X[2];
     H[1] = c2 * X[3];
@@ -117,15 +230,15 @@ struct MediumDev {
 };
 
 template <int MED>
-__device__ __forceinline__ void rhs(const MediumDev &m, const double *pt, const double X[4], double H[4], int &oob)
+__device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], int &oob)
 {
-    if (MED == kGrid) rhs_grid(m.g, pt, X, H, oob);
+    if (MED == kGrid) rhs_grid<true>(m.g, pt, X, H, oob);
     else rhs_sinprod(m.sp, X, H);
 }
 
 // classical RK4, a6/a7 form: k = H*dt; X + k1/2; ...; /6.0       NonObstacle.jl:72-76
 template <int MED>
-__device__ __forceinline__ void rk4_kdt(const MediumDev &m, const double *pt, double X[4], double dt, int &oob)
+__device__ __forceinline__ void rk4_kdt(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
 {
     double H[4], Y[4], acc[4];
     rhs<MED>(m, pt, X, H, oob);
@@ -139,12 +252,12 @@ __device__ __forceinline__ void rk4_kdt(const MediumDev &m, const double *pt, do
     for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = acc[k] + 2 * kk; Y[k] = X[k] + kk; }
     rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; X[k] = X[k] + div6(acc[k] + kk); }
+    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
 }
 
 // a8/a9 form: k = H; X + k/2*dt; X += (k1+2k2+2k3+k4)*dt/6.0     NonObstacle.jl:161-164,171
 template <int MED>
-__device__ __forceinline__ void rk4_k(const MediumDev &m, const double *pt, double X[4], double dt, int &oob)
+__device__ __forceinline__ void rk4_k(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
 {
     double H[4], Y[4], acc[4];
     rhs<MED>(m, pt, X, H, oob);
@@ -158,7 +271,7 @@ __device__ __forceinline__ void rk4_k(const MediumDev &m, const double *pt, doub
     for (int k = 0; k < 4; ++k) { acc[k] = acc[k] + 2 * H[k]; Y[k] = X[k] + H[k] * dt; }
     rhs<MED>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) X[k] = X[k] + div6((acc[k] + H[k]) * dt);
+    for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
 }
 
 __device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(a * a + b * b); }
