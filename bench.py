@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", choices=["fused", "exact"], default="fused",
+                    help="arithmetic flavour of the gridded kernels (include/ray_amd.h); fused is the library default")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,6 +83,7 @@ def main():
     ctx = ray_amd.Context(local)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_arith(ray_amd.ARITH_FUSED if args.arith == "fused" else ray_amd.ARITH_EXACT)
 
     # synthetic medium: c = 1 + 0.3 sin(1.5 pi x) sin(1.5 pi y) on linspace(-1.5,1.5,512)^2
     sp = ray_amd.SinProd.smooth_demo()
@@ -154,7 +157,7 @@ def main():
             "config": {"workload": "forward shooting to exit, 2048x2048 (theta,phi) rays per GPU, "
                                    "512^2 fp64 wavespeed grid, dt=1e-2 (BASELINE configs[1]) + misfit "
                                    "reduction" + (" + 1 all-reduce" if world > 1 else ""),
-                       "ns_total": ns_total, "nd": ND, "grid": NGRID, "dt": DT,
+                       "arith": args.arith, "ns_total": ns_total, "nd": ND, "grid": NGRID, "dt": DT,
                        "rays_per_gpu": num, "mean_steps_per_ray": steps_per_launch / num,
                        "parallelism": f"theta-block x{world}"},
             "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",

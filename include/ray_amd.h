@@ -63,6 +63,16 @@ int         ray_ctx_destroy(ray_ctx *ctx);
 /* borrow a caller-owned hipStream_t (pass NULL to return to the context's own stream) */
 int         ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream);
 int         ray_ctx_synchronize(ray_ctx *ctx);
+/* Arithmetic flavour of the gridded kernels (DiscreteHamilton NonObstacle.jl:30-42 + the RK4
+ * combinations NonObstacle.jl:72-76,161-171).  The reference evaluates them under @fastmath, so its
+ * own results are defined only up to multiply-add contraction:
+ *   RAY_ARITH_EXACT  every operator one IEEE rounding in the reference's order (= un-fused code)
+ *   RAY_ARITH_FUSED  multiply-adds contracted (default; ~1.5x fewer fp64 instructions; differs
+ *                    from EXACT by rounding only: ~1e-12 relative on exit states, bound 1e-10)
+ * Analytic media, exit/reflection bisections and the misfit are identical in both.             */
+#define RAY_ARITH_EXACT 0
+#define RAY_ARITH_FUSED 1
+int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
 
 /* out[k] = linspace(a, b, n)[k+1] exactly as the library (and Julia's TwicePrecision ranges,
  * NonObstacle.jl:55-56,191) evaluates it: the correctly rounded a + k(b-a)/(n-1).  Host only;

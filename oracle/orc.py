@@ -27,7 +27,7 @@ class Obstacle(C.Structure):
 
 class Medium(C.Structure):
     _fields_ = [("kind", C.c_int), ("sp", SinProd), ("N", C.c_int), ("ext", C.c_double),
-                ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p)]
+                ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p), ("arith", C.c_int)]
 
 
 def build():
@@ -74,7 +74,9 @@ def sinprod_grid(params, N, ext):
 
 
 class GridTables:
-    def __init__(self, c, ext):
+    def __init__(self, c, ext, arith=0):
+        """arith: 0 = as-written (un-fused) arithmetic, 1 = the "fused" flavour (ray_oracle.c)."""
+        self.arith = int(arith)
         c = np.asfortranarray(c, dtype=np.float64)
         N = c.shape[0]
         assert c.shape == (N, N)
@@ -89,7 +91,15 @@ class GridTables:
         m.kind = 1
         m.N, m.ext = self.N, self.ext
         m.eval, m.grad, m.p = _dp(self.eval), _dp(self.grad), _dp(self.p)
+        m.arith = self.arith
         return m
+
+    def with_arith(self, arith):
+        """Same tables, other arithmetic flavour (shares the arrays)."""
+        import copy
+        t = copy.copy(self)
+        t.arith = int(arith)
+        return t
 
 
 def analytic_medium(params):
@@ -147,7 +157,7 @@ def trace_fixed_time(tab, m_in, dt, mode, nthreads=1):
     st = np.zeros(num, dtype=np.int32)
     ns_ = np.zeros(num, dtype=np.int32)
     lib().orc_trace_fixed_time(_dp(tab.eval), _dp(tab.grad), _dp(tab.p), C.c_int(tab.N),
-                               C.c_double(dt), C.c_int(mode), _dp(m_in), C.c_int64(num),
+                               C.c_double(dt), C.c_int(mode), C.c_int(tab.arith), _dp(m_in), C.c_int64(num),
                                C.c_int64(num), _dp(X), C.c_int64(num), _dp(st), _dp(ns_),
                                C.c_int(nthreads))
     return X, st, ns_

@@ -156,6 +156,71 @@ int orc_discrete_hamilton(const double X[4], const double *eval, const double *g
     return oob;
 }
 
+/* ---- "fused" flavour --------------------------------------------------------------------------
+ * The reference evaluates these functions under @fastmath (NonObstacle.jl:1,6,30,54), which lets
+ * the compiler contract a*b+c into one fused multiply-add.  This flavour spells out one such
+ * contraction explicitly (the one the HIP kernels use in RAY_ARITH_FUSED), so that the kernel
+ * can be checked bit for bit; against the as-written flavour above it differs by rounding only.
+ *   cell index  floor(fma(x, rh, nb)),  rh = 1/h, nb = -p[1]*rh
+ *   dot         fma(dxdy, t3, fma(dy, t2, fma(dx, t1, t0)))
+ *   tau         fma(py, py, px*px);  H[2:3] = (-g) * (c*tau)
+ *   RK4         Y = fma(H, dt/2, X) / fma(H, dt, X);  acc = fma(2, H, acc);
+ *               X += fma(acc + H4, dt*RN(1/6), X)                                              */
+static int cell_index_fused(double x, double rh, double nb, int N, int *oob)
+{
+    double q = floor(fma(x, rh, nb));
+    int I;
+    if (!(q >= 0.0)) { I = 1; *oob = 1; }
+    else if (q > (double)(N - 3)) { I = N - 2; *oob = 1; }
+    else I = (int)q + 1;
+    return I;
+}
+static double zdot_fused(double dx, double dy, double dxdy, const double *tab, int64_t base,
+                         int64_t plane, int k0)
+{
+    return fma(dxdy, tab[base + (k0 + 3) * plane],
+               fma(dy, tab[base + (k0 + 2) * plane],
+                   fma(dx, tab[base + (k0 + 1) * plane], tab[base + (k0 + 0) * plane])));
+}
+int orc_discrete_hamilton_fused(const double X[4], const double *eval, const double *grad,
+                                const double *p, int N, double H[4])
+{
+    int oob = 0;
+    const int64_t n1 = N - 1, n2 = N - 2;
+    double h = p[1] - p[0];
+    double rh = 1.0 / h, nb = -p[0] * rh;
+    int I = cell_index_fused(X[0], rh, nb, N, &oob);
+    int J = cell_index_fused(X[1], rh, nb, N, &oob);
+    double dx = X[0] - p[I - 1], dy = X[1] - p[J - 1];
+    double dxdy = dx * dy;
+    double tau = fma(X[3], X[3], X[2] * X[2]);
+    double c = zdot_fused(dx, dy, dxdy, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
+    double gcX = zdot_fused(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 0);
+    double gcY = zdot_fused(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 4);
+    double c2 = c * c, w = c * tau;
+    H[0] = c2 * X[2];
+    H[1] = c2 * X[3];
+    H[2] = (-gcX) * w;
+    H[3] = (-gcY) * w;
+    return oob;
+}
+static int rk4_step_fused(const double *eval, const double *grad, const double *p, int N,
+                          double X[4], double dt)
+{
+    double H[4], Y[4], acc[4];
+    const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
+    int oob = 0;
+    oob |= orc_discrete_hamilton_fused(X, eval, grad, p, N, H);
+    for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma(H[k], hdt, X[k]); }
+    oob |= orc_discrete_hamilton_fused(Y, eval, grad, p, N, H);
+    for (int k = 0; k < 4; ++k) { acc[k] = fma(2.0, H[k], acc[k]); Y[k] = fma(H[k], hdt, X[k]); }
+    oob |= orc_discrete_hamilton_fused(Y, eval, grad, p, N, H);
+    for (int k = 0; k < 4; ++k) { acc[k] = fma(2.0, H[k], acc[k]); Y[k] = fma(H[k], dt, X[k]); }
+    oob |= orc_discrete_hamilton_fused(Y, eval, grad, p, N, H);
+    for (int k = 0; k < 4; ++k) X[k] = fma(acc[k] + H[k], dt6, X[k]);
+    return oob;
+}
+
 /* gridded c(x,y) alone: z' * eval[I,J,:] (used for c(sensor) when shooting on a grid) */
 static double grid_speed(double x, double y, const double *eval, const double *p, int N, int *oob)
 {
@@ -244,6 +309,8 @@ static int rk4_step_kdt(const orc_medium *med, double X[4], double dt)
 {
     double k1[4], k2[4], k3[4], k4[4], Y[4], H[4];
     int oob = 0;
+    if (med->kind == 1 && med->arith == 1)
+        return rk4_step_fused(med->eval, med->grad, med->p, med->N, X, dt);
     oob |= rhs(med, X, H);
     for (int k = 0; k < 4; ++k) { k1[k] = H[k] * dt; Y[k] = X[k] + k1[k] / 2; }
     oob |= rhs(med, Y, H);
@@ -357,8 +424,8 @@ static int rk4_step_k(const double *eval, const double *grad, const double *p, i
 #define ORC_FIXED_STEP_CAP 10000000
 
 void orc_trace_fixed_time(const double *eval, const double *grad, const double *p, int N,
-                          double timeStep, int mode, const double *m_in, int64_t num, int64_t ld,
-                          double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
+                          double timeStep, int mode, int arith, const double *m_in, int64_t num,
+                          int64_t ld, double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
                           int nthreads)
 {
     (void)nthreads;
@@ -374,7 +441,7 @@ void orc_trace_fixed_time(const double *eval, const double *grad, const double *
             if (steps >= ORC_FIXED_STEP_CAP) { st |= ORC_ST_STEP_CAP; break; }
             if (mode == 0 && (t + dt) > Ti) dt = Ti - t;          /* NonObstacle.jl:153-156 */
             t = t + dt;                                           /* :157 / Obstacle.jl:311 */
-            if (rk4_step_k(eval, grad, p, N, X, dt)) st |= ORC_ST_OOB;
+            if (arith ? rk4_step_fused(eval, grad, p, N, X, dt) : rk4_step_k(eval, grad, p, N, X, dt)) st |= ORC_ST_OOB;
             ++steps;
             if (mode == 0 && norm2(X[0], X[1]) > cease_r) {       /* NonObstacle.jl:177-181 */
                 t = t + (Ti - t);

@@ -50,6 +50,7 @@ typedef struct {
     orc_sinprod sp;
     int N; double ext;     /* grid */
     const double *eval, *grad, *p;
+    int arith;             /* grid only: 0 = as written (un-fused), 1 = "fused" flavour (ray_oracle.c) */
 } orc_medium;
 
 void   orc_linspace(double a, double b, int n, double *out);
@@ -57,6 +58,8 @@ void   orc_q4(const double *c, int N, int I, int J, double dx, double q[4]);
 void   orc_build_tables(const double *c, int N, double ext, double *eval, double *grad);
 int    orc_discrete_hamilton(const double X[4], const double *eval, const double *grad,
                              const double *p, int N, double H[4]);
+int    orc_discrete_hamilton_fused(const double X[4], const double *eval, const double *grad,
+                                   const double *p, int N, double H[4]);
 void   orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4]);
 
 /* initial boundary phase-space grid, rows for sources [src_begin, src_end) */
@@ -71,7 +74,7 @@ void   orc_shoot(const orc_medium *med, const orc_obstacle *ob, double dt, int t
 
 /* a8 (mode 1: overshoot) / a9 X-only (mode 0: shorten last step + cease) */
 void   orc_trace_fixed_time(const double *eval, const double *grad, const double *p, int N,
-                            double dt, int mode, const double *m_in, int64_t num, int64_t ld,
+                            double dt, int mode, int arith, const double *m_in, int64_t num, int64_t ld,
                             double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
                             int nthreads);
 

@@ -24,7 +24,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import (RayError, ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED,
-                   TIME_SECONDS, TIME_STEPS, TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT)
+                   TIME_SECONDS, TIME_STEPS, TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT,
+                   ARITH_EXACT, ARITH_FUSED)
 
 __all__ = ["Context", "SinProd", "Circle", "GridMedium", "ScatterRelation",
            "ScatterRelationObstacle", "ScatterForwardOperator", "NonReflectionTrace", "misfit",
@@ -61,6 +62,11 @@ class Context:
 
     def set_stream(self, hip_stream):
         _lib.check(self._lib.ray_ctx_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+
+    def set_arith(self, arith):
+        """ARITH_EXACT (un-fused, bit-identical to the as-written CPU restatement) or
+        ARITH_FUSED (default: multiply-adds contracted)."""
+        _lib.check(self._lib.ray_ctx_set_arith(self.handle, int(arith)))
 
     def enable_timing(self, on=True):
         _lib.check(self._lib.ray_ctx_enable_timing(self.handle, int(bool(on))))

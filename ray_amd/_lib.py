@@ -11,6 +11,7 @@ ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED = 0x01, 0x02, 0x04, 0x0
 OB_NONE, OB_CIRCLE = 0, 1
 TIME_SECONDS, TIME_STEPS = 0, 1
 TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT = 0, 1
+ARITH_EXACT, ARITH_FUSED = 0, 1
 
 
 class RayError(RuntimeError):
@@ -45,6 +46,7 @@ SIGNATURES = {
     "ray_ctx_destroy": [_vp],
     "ray_ctx_set_stream": [_vp, _vp],
     "ray_ctx_synchronize": [_vp],
+    "ray_ctx_set_arith": [_vp, C.c_int],
     "ray_medium_create_grid": [_vp, _vp, C.c_int, _f64, C.POINTER(_vp)],
     "ray_medium_update_grid": [_vp, _vp],
     "ray_medium_update_grid_dev": [_vp, _vp],

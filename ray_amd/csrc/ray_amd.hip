@@ -83,11 +83,6 @@ struct ShootArgs {
 
 __device__ __forceinline__ double ob_val(double r0, double x, double y) { return norm2(x, y) - r0; }
 
-// a6 / a7: ScatterRelation / ScatterRelationObstacle per-ray loop.
-// NonObstacle.jl:67-97; Obstacle.jl:23-95.  Lanes = consecutive directions of one source, so a
-// wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
-// The exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
-// wavefront has left the disk and is then run by all lanes at once.
 __device__ __forceinline__ void lerp4(double E[4], const double P[4], const double X[4], double mid)
 {
 #pragma unroll
@@ -97,12 +92,16 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 // a6 / a7: ScatterRelation / ScatterRelationObstacle per-ray loop.
 // NonObstacle.jl:67-97; Obstacle.jl:23-95.  Lanes = consecutive directions of one source, so a
 // wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
-//  - the RK4 step is executed by ALL 64 lanes while any lane of the wavefront is alive (finished
-//    lanes integrate their frozen state and discard the result): the gridded right-hand side
-//    fetches cell records wave-cooperatively (ray_device.h) and needs the wave converged;
+//  - the RK4 step is executed by ALL 64 lanes while any lane of the wavefront is alive: the
+//    gridded right-hand side fetches cell records wave-cooperatively (ray_device.h) and needs the
+//    wave converged.  A finished lane steps with dt = 0, which leaves its state bit-for-bit in
+//    place next to its still-running neighbours (no per-component select);
+//  - all lanes of a wave start together, so elapsed time and step count are wave-uniform until a
+//    lane leaves: they are kept once per wave and latched by each lane at its exit;
 //  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
-//    wavefront has left the disk and is then run by all lanes at once.
-template <int MED, int OB>
+//    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
+//    parked in the output row meanwhile.
+template <int MED, int OB, int AR>
 __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
@@ -151,73 +150,74 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
         }
-        if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;    // NaN position: see cell0()
+        if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;    // NaN position: see cell_of()
     }
-    double t = 0;
-    int steps = 0, nref = 0, rfl = 0;
-    bool active = valid;
     const double dt = a.dt;
+    double tw = 0, t = 0;          // tw: wave-uniform clock; t: this lane's, latched at its exit
+    int it = 0, steps = 0;         // it: wave-uniform step count
+    int nref = 0, rfl = 0;
+    bool active = valid;
     while (__any(active)) {
+        if (it >= a.max_steps) break;                       // wave-uniform; live lanes get STEP_CAP below
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
         double Xn[4];
         int o = 0;
-        rk4_kdt<MED>(a.med, acc, X, Xn, dt, o);
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, active ? dt : 0.0, o);
+        ++it;
+        tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
+        // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
+        const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
-            double P[4];                       // state before the step (NonObstacle.jl:71 `prev`)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { P[k] = X[k]; X[k] = Xn[k]; }
-            ++steps;
-            t = a.time_unit ? t + 1 : t + dt;
-            // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
-            const double s = X[0] * X[0] + X[1] * X[1];
             oob |= o | !(s == s);
             if (s >= 1.0) {
-                // parked in the output row until the deferred bisection below picks it up
+                // pre-step state (NonObstacle.jl:71 `prev`) parked in the output row until the
+                // deferred bisection below picks it up
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = P[k];
+                for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];
+                t = tw; steps = it;
                 st |= kStExited; active = false;
-            } else {
-                if (OB == kObCircle) {
-                    if (ob_val(a.ob_r0, X[0], X[1]) <= 0 && rfl == 0) {          // Obstacle.jl:69-91
-                        double lo = 0, hi = 1, mid = 0.5, E[4], e;
-                        int it = 0;
-                        rfl = 1;
-                        lerp4(E, P, X, mid);
+            } else if (OB == kObCircle) {
+                if (ob_val(a.ob_r0, Xn[0], Xn[1]) <= 0 && rfl == 0) {            // Obstacle.jl:69-91
+                    double lo = 0, hi = 1, mid = 0.5, E[4], e;
+                    int ib = 0;
+                    rfl = 1;
+                    lerp4(E, X, Xn, mid);
+                    e = ob_val(a.ob_r0, E[0], E[1]);
+                    while (__builtin_fabs(e) > 1e-15) {
+                        if (++ib > kBisectCap) { st |= kStBisectCap; break; }
+                        if (e > 0) lo = mid; else hi = mid;
+                        mid = (lo + hi) * 0.5;
+                        lerp4(E, X, Xn, mid);
                         e = ob_val(a.ob_r0, E[0], E[1]);
-                        while (__builtin_fabs(e) > 1e-15) {
-                            if (++it > kBisectCap) { st |= kStBisectCap; break; }
-                            if (e > 0) lo = mid; else hi = mid;
-                            mid = (lo + hi) * 0.5;
-                            lerp4(E, P, X, mid);
-                            e = ob_val(a.ob_r0, E[0], E[1]);
-                        }
-                        // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
-                        const double rr = norm2(E[0], E[1]);
-                        double nx = E[0] / rr, ny = E[1] / rr;
-                        const double nn = norm2(nx, ny);
-                        nx = nx / nn; ny = ny / nn;
-                        const double a0 = 2 * nx, a1 = 2 * ny;
-                        const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
-                        const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
-                        X[0] = E[0]; X[1] = E[1];
-                        X[2] = m11 * E[2] + m12 * E[3];
-                        X[3] = m21 * E[2] + m22 * E[3];
-                        ++nref;
                     }
+                    // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
+                    const double rr = norm2(E[0], E[1]);
+                    double nx = E[0] / rr, ny = E[1] / rr;
+                    const double nn = norm2(nx, ny);
+                    nx = nx / nn; ny = ny / nn;
+                    const double a0 = 2 * nx, a1 = 2 * ny;
+                    const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
+                    const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
+                    Xn[0] = E[0]; Xn[1] = E[1];
+                    Xn[2] = m11 * E[2] + m12 * E[3];
+                    Xn[3] = m21 * E[2] + m22 * E[3];
+                    ++nref;
                 }
-                if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = Xn[k];
     }
+    if (active) { st |= kStStepCap; t = tw; steps = it; }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
         double lo = 0, hi = 1, mid = 0.5, E[4], e, P[4];
-        int it = 0;
+        int ib = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) P[k] = a.m[r + (4 + k) * a.ld];
         lerp4(E, P, X, mid);
         e = norm2(E[0], E[1]) - 1;
         while (__builtin_fabs(e) > 1e-15) {
-            if (++it > kBisectCap) { st |= kStBisectCap; break; }
+            if (++ib > kBisectCap) { st |= kStBisectCap; break; }
             if (e > 0) hi = mid; else lo = mid;
             mid = (lo + hi) * 0.5;
             lerp4(E, P, X, mid);
@@ -255,7 +255,9 @@ struct TraceArgs {
 };
 
 // a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
-// NonObstacle.jl:146-157,161-164,171,177-181,185).
+// NonObstacle.jl:146-157,161-164,171,177-181,185).  Same wave-converged stepping as k_shoot;
+// the clock is per lane here (every ray has its own T and its own shortened last step).
+template <int AR>
 __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     const GridAcc acc = grid_acc_setup(a.med.g);
     double X[4] = {0, 0, 1, 0};
     double T = 0;
-    int steps = 0, st = 0, oob = 0;
+    int steps = 0, st = 0, oob = 0, it = 0;
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
@@ -272,22 +274,21 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     }
     double t = 0, dt = a.dt;
     bool active = valid && t < T;
-    while (__any(active)) {                     // all lanes step together (cooperative fetch)
+    while (__any(active)) {
+        if (it >= a.max_steps) break;
+        double dtl = 0.0;
         if (active) {
-            if (steps >= a.max_steps) { st |= kStStepCap; active = false; }
-            else {
-                if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;
-                t = t + dt;
-            }
+            if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;    // NonObstacle.jl:153-156
+            t = t + dt;
+            dtl = dt;
         }
         double Xn[4];
         int o = 0;
-        rk4_k<kGrid>(a.med, acc, X, Xn, dt, o);
+        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, o);
+        ++it;
+        const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-            ++steps;
-            const double s = X[0] * X[0] + X[1] * X[1];
+            steps = it;
             oob |= o | !(s == s);
             if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
                 // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
@@ -297,11 +298,14 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
                 if (s > c2 * 1.0000000001) out = true;
                 else if (s < c2 * 0.9999999999) out = false;
                 else out = __builtin_sqrt(s) > a.cease_r;
-                if (out) { t = t + (T - t); st |= kStCeased; }
+                if (out) { t = t + (T - t); st |= kStCeased; }                    // NonObstacle.jl:177-181
             }
             active = t < T;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = Xn[k];
     }
+    if (active) st |= kStStepCap;
     if (oob) st |= kStOob;
     if (valid) {
 #pragma unroll
@@ -405,6 +409,7 @@ struct ray_ctx {
     unsigned long long *d_steps = nullptr;     // device ray-step counter
     double *d_partial = nullptr;               // misfit partials, 2*kMisfitBlocks
     uint64_t rays = 0, launches = 0;
+    int arith = RAY_ARITH_FUSED;
     bool timing = false;
     double kernel_ms = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -703,6 +708,7 @@ static MediumDev medium_dev(const ray_medium *m)
         d.g.p1 = m->p[0];
         d.g.h = m->p[1] - m->p[0];                                      // NonObstacle.jl:32
         d.g.rh = 1.0 / d.g.h;
+        d.g.nb = -d.g.p1 * d.g.rh;
     }
     return d;
 }
@@ -745,12 +751,18 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     if (lds > 160 * 1024) return fail(RAY_ERR_UNSUPPORTED, "grid too large for the LDS node table");
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
+    const bool fused = ctx->arith == RAY_ARITH_FUSED;
     if (med->kind == kGrid) {
-        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kGrid, kObNone>), grid, block, lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle>), grid, block, lds, ctx->stream, a);
+        if (obk == RAY_OB_NONE) {
+            if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kFused>), grid, block, lds, ctx->stream, a);
+            else hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kExact>), grid, block, lds, ctx->stream, a);
+        } else {
+            if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kFused>), grid, block, lds, ctx->stream, a);
+            else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kExact>), grid, block, lds, ctx->stream, a);
+        }
     } else {
-        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle>), grid, block, 0, ctx->stream, a);
+        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone, kExact>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle, kExact>), grid, block, 0, ctx->stream, a);
     }
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
@@ -922,7 +934,9 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
     a.step_counter = ctx->d_steps;
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    hipLaunchKernelGGL(k_trace, dim3((unsigned)((num + block_threads() - 1) / block_threads())), dim3(block_threads()), nodes_lds_bytes(med), ctx->stream, a);
+    const dim3 tgrid((unsigned)((num + block_threads() - 1) / block_threads())), tblock(block_threads());
+    if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_trace<kFused>, tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+    else hipLaunchKernelGGL(k_trace<kExact>, tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)num;
@@ -992,6 +1006,14 @@ int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64
     if (mask && num) HIPCHK(hipMemcpyAsync(mask, dmask.p, (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     if (mismatch && num) HIPCHK(hipMemcpyAsync(mismatch, dmis.p, sizeof(double) * 4 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+int ray_ctx_set_arith(ray_ctx *ctx, int arith)
+{
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    if (arith != RAY_ARITH_EXACT && arith != RAY_ARITH_FUSED) return fail(RAY_ERR_INVALID, "bad arith");
+    ctx->arith = arith;
     return RAY_OK;
 }
 

@@ -29,6 +29,7 @@ struct GridDev {
     double p1;           // p[1] = -ext
     double h;            // p[2] - p[1]            (NonObstacle.jl:32)
     double rh;           // RN(1/h), for the Markstein quotient
+    double nb;           // RN(-p1*rh): kFused cell index = floor(fma(x, rh, nb))
 };
 struct SinProdDev { double A, wx, wy, gx, gy; };
 
@@ -87,21 +88,10 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     return a;
 }
 
-// I-1 for I = Int64(floor((x - p[1])/h)) + 1, clamped to the cells whose grad entry exists
-// (reference: undefined behaviour outside; here flagged).            NonObstacle.jl:33-34
+// Cell index I-1 for I = Int64(floor((x - p[1])/h)) + 1 (NonObstacle.jl:33-34), clamped to the
+// cells whose grad entry exists (reference: undefined behaviour outside; here flagged): cell_of().
 // v_cvt_i32_f64 saturates and maps NaN to 0; a NaN position is flagged by the callers' own
 // per-step check, so the flag word equals the CPU restatement's in every case.
-__device__ __forceinline__ int cell0(double x, const GridDev &g, int &oob)
-{
-    const double q = __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
-    int iraw;                                    // saturating; (int)q would be UB out of range
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
-    int i;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
-    oob |= (i != iraw);
-    return i;
-}
-
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
@@ -161,41 +151,73 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     for (int k = 0; k < 6; ++k) out[k] = r[k];
 }
 
+// ---- arithmetic flavours of the gridded right-hand side and RK4 combination -----------------
+// kExact : every operator of the reference's expressions is one IEEE rounding, in the reference's
+//          order (bit-identical to the un-fused CPU restatement, oracle/ray_oracle.c).  fma is used
+//          only where it provably returns the same bits: x + k*0.5, acc + 2*k (the product is exact)
+//          and the two Markstein quotients (header comment).
+// kFused : the same formulas with multiply-adds contracted, as a compiler is free to do under the
+//          reference's @fastmath (NonObstacle.jl:1,6,30,54): Horner dot products, H*(dt/2) folded
+//          into the stage update, one multiply by RN(1/h) for the cell index.  Differs from kExact
+//          by rounding only (~1e-12 relative on exits, tests/test_gpu_parity.py) and is itself
+//          bit-identical to the oracle's "fused" flavour, which spells out the same contractions.
+enum Arith { kExact = 0, kFused = 1 };
+
+template <int AR>
+__device__ __forceinline__ int cell_of(double x, const GridDev &g, int &oob)
+{
+    const double q = (AR == kFused) ? __builtin_floor(__builtin_fma(x, g.rh, g.nb))
+                                    : __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
+    int iraw, i;                                 // v_cvt saturates; (int)q would be UB out of range
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
+    oob |= (i != iraw);
+    return i;
+}
+
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
-// COOP: all 64 lanes are converged here -> wave-cooperative record fetch; otherwise per-lane loads.
-template <bool COOP>
+// ALL 64 lanes must be converged here (wave-cooperative record fetch).
+template <int AR>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], int &oob)
 {
-    const int i = cell0(X[0], g, oob);
-    const int j = cell0(X[1], g, oob);
+    const int i = cell_of<AR>(X[0], g, oob);
+    const int j = cell_of<AR>(X[1], g, oob);
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
     const double *pt = lds_nodes();
     const double pi_ = pt[i], pj_ = pt[j];
     double2 r[6];
-    if (COOP) fetch_records(g, a, cid, r);
-    else {
-        const double2 *src = reinterpret_cast<const double2 *>(g.rec) + (size_t)cid * 6;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) r[k] = src[k];
-    }
+    fetch_records(g, a, cid, r);
     const double dx = X[0] - pi_, dy = X[1] - pj_;
     const double dxdy = dx * dy;
-    const double tau = X[2] * X[2] + X[3] * X[3];
-    const double c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
-    const double gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
-    const double gcY = ((r[4].x + dx * r[4].y) + dy * r[5].x) + dxdy * r[5].y;
-    const double c2 = c * c;
-    H[0] = c2 * X[2];
-    H[1] = c2 * X[3];
-    H[2] = ((-gcX) * c) * tau;
-    H[3] = ((-gcY) * c) * tau;
+    if (AR == kFused) {
+        const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
+        const double c = __builtin_fma(dxdy, r[1].y, __builtin_fma(dy, r[1].x, __builtin_fma(dx, r[0].y, r[0].x)));
+        const double gcX = __builtin_fma(dxdy, r[3].y, __builtin_fma(dy, r[3].x, __builtin_fma(dx, r[2].y, r[2].x)));
+        const double gcY = __builtin_fma(dxdy, r[5].y, __builtin_fma(dy, r[5].x, __builtin_fma(dx, r[4].y, r[4].x)));
+        const double c2 = c * c, w = c * tau;
+        H[0] = c2 * X[2];
+        H[1] = c2 * X[3];
+        H[2] = (-gcX) * w;
+        H[3] = (-gcY) * w;
+    } else {
+        const double tau = X[2] * X[2] + X[3] * X[3];
+        const double c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
+        const double gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
+        const double gcY = ((r[4].x + dx * r[4].y) + dy * r[5].x) + dxdy * r[5].y;
+        const double c2 = c * c;
+        H[0] = c2 * X[2];
+        H[1] = c2 * X[3];
+        H[2] = ((-gcX) * c) * tau;
+        H[3] = ((-gcY) * c) * tau;
+    }
 }
 
 // z' * eval[I,J,:] alone (c at the sensor for the initial slowness)  NonObstacle.jl:39,62
+// per-lane loads (called under divergence, once per ray); as-written arithmetic in both flavours
 __device__ __forceinline__ double speed_grid(const GridDev &g, const double *pt, double x, double y, int &oob)
 {
-    const int i = cell0(x, g, oob);
-    const int j = cell0(y, g, oob);
+    const int i = cell_of<kExact>(x, g, oob);
+    const int j = cell_of<kExact>(y, g, oob);
     const double2 *r = reinterpret_cast<const double2 *>(g.rec) +
                        ((size_t)i + (size_t)j * (size_t)(g.N - 1)) * 6;
     const double2 e01 = r[0], e23 = r[1];
@@ -229,49 +251,63 @@ struct MediumDev {
     SinProdDev sp;
 };
 
-template <int MED>
+template <int MED, int AR>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], int &oob)
 {
-    if (MED == kGrid) rhs_grid<true>(m.g, pt, X, H, oob);
+    if (MED == kGrid) rhs_grid<AR>(m.g, pt, X, H, oob);
     else rhs_sinprod(m.sp, X, H);
 }
 
-// classical RK4, a6/a7 form: k = H*dt; X + k1/2; ...; /6.0       NonObstacle.jl:72-76
-template <int MED>
-__device__ __forceinline__ void rk4_kdt(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
+// One classical RK4 step X -> Xn with step dt (dt == 0 leaves Xn == X: how finished lanes idle).
+// FORM 0 = a6/a7: k = H*dt; X + k1/2; (k1+2k2+2k3+k4)/6.0         NonObstacle.jl:72-76
+// FORM 1 = a8/a9: k = H;    X + k/2*dt; (k1+2k2+2k3+k4)*dt/6.0    NonObstacle.jl:161-164,171
+// kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)
+template <int MED, int AR, int FORM>
+__device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
 {
     double H[4], Y[4], acc[4];
-    rhs<MED>(m, pt, X, H, oob);
+    if (AR == kFused && MED == kGrid) {
+        const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
+        rhs<MED, AR>(m, pt, X, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = X[k] + kk * 0.5; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = __builtin_fma(H[k], hdt, X[k]); }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = acc[k] + 2 * kk; Y[k] = X[k] + kk * 0.5; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = __builtin_fma(H[k], hdt, X[k]); }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = acc[k] + 2 * kk; Y[k] = X[k] + kk; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = __builtin_fma(H[k], dt, X[k]); }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
-}
-
-// a8/a9 form: k = H; X + k/2*dt; X += (k1+2k2+2k3+k4)*dt/6.0     NonObstacle.jl:161-164,171
-template <int MED>
-__device__ __forceinline__ void rk4_k(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
-{
-    double H[4], Y[4], acc[4];
-    rhs<MED>(m, pt, X, H, oob);
+        for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
+    } else if (FORM == 0) {
+        rhs<MED, AR>(m, pt, X, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + (H[k] * 0.5) * dt; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { acc[k] = acc[k] + 2 * H[k]; Y[k] = X[k] + (H[k] * 0.5) * dt; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { acc[k] = acc[k] + 2 * H[k]; Y[k] = X[k] + H[k] * dt; }
-    rhs<MED>(m, pt, Y, H, oob);
+        for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
+        rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
+        for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
+    } else {
+        const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
+        rhs<MED, AR>(m, pt, X, H, oob);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
+        rhs<MED, AR>(m, pt, Y, H, oob);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
+        rhs<MED, AR>(m, pt, Y, H, oob);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
+        rhs<MED, AR>(m, pt, Y, H, oob);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
+    }
 }
 
 __device__ __forceinline__ double norm2(double a, double b) { return __builtin_sqrt(a * a + b * b); }

@@ -1,9 +1,15 @@
 """GPU parity: the HIP path (through the C ABI, ctypes) against the CPU oracle and the committed
 golden fixtures.  Bars (north_star): <= 1e-10 relative on exit coordinates and traveltime;
-status / step count / reflection count identical.  Where the kernel's arithmetic is the same
-un-fused fp64 sequence as the oracle's (gridded media from explicit states, fixed-time traces,
-tables) the comparison is BIT-EXACT.  The only non-bit-exact inputs are device sin/cos (initial
-direction, analytic media) against the host libm."""
+status / step count / reflection count identical.
+
+Gridded kernels come in two arithmetic flavours (include/ray_amd.h, ray_ctx_set_arith):
+  exact : the reference's expressions un-fused -> BIT-EXACT against the as-written oracle and the
+          golden fixtures (gridded media from explicit states, fixed-time traces, tables);
+  fused : multiply-adds contracted (the default) -> BIT-EXACT against the oracle's "fused" flavour,
+          and within RTOL of the as-written oracle / golden fixtures with identical
+          status / step / reflection counts.
+The only non-bit-exact inputs are device sin/cos (initial direction, analytic media) against the
+host libm."""
 import math
 
 import numpy as np
@@ -14,6 +20,15 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
+
+
+@pytest.fixture(params=[0, 1], ids=["exact", "fused"])
+def arith(ctx, request):
+    """Selects the kernels' arithmetic flavour for one test; returns 0 (exact) / 1 (fused)."""
+    import ray_amd
+    ctx.set_arith(request.param)
+    yield request.param
+    ctx.set_arith(ray_amd.ARITH_FUSED)
 
 
 def rel_err(a, b):
@@ -79,25 +94,28 @@ def test_scatter_obstacle_golden(ctx):
     assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
 
 
-def test_grid_golden(ctx):
+def test_grid_golden(ctx, arith):
     import ray_amd
     g = golden("grid_n75_ns8_nd16.npz")
+    exact = arith == 0
     med = ray_amd.GridMedium(g["c"], float(g["ext"]), ctx)
     m, info = ray_amd.ScatterRelation(med, None, int(g["ns"]), int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
     assert_rays(m, info, g["m"], g["status"], g["nsteps"])
-    # explicit states: bit-exact
+    # explicit states: bit-exact in the exact flavour
     m2 = np.asfortranarray(g["m"].copy())
     m2[:, 4:] = 0
     info2 = ray_amd.shoot_states(med, m2, float(g["dt"]), ctx=ctx)
-    assert_rays(m2, info2, g["m"], g["status"], g["nsteps"], exact=True)
-    # a9 / a8 fixed-time traces from the golden states: bit-exact
+    assert_rays(m2, info2, g["m"], g["status"], g["nsteps"], exact=exact)
+    # a9 / a8 fixed-time traces from the golden states
     _, s, inf = ray_amd.ScatterForwardOperator(med, g["m"], float(g["ext"]), float(g["trace_dt"]), ctx=ctx, info=True)
-    assert np.array_equal(s[:, 4:8], g["X_shorten"])
+    assert np.array_equal(s[:, 4:8], g["X_shorten"]) if exact else rel_err(s[:, 4:8], g["X_shorten"]) <= RTOL
     assert np.array_equal(inf["status"], g["st_shorten"]) and np.array_equal(inf["nsteps"], g["ns_shorten"])
     assert np.array_equal(s[:, 0:4], g["m"][:, 0:4]) and np.array_equal(s[:, 8], g["m"][:, 8])
     out, inf = ray_amd.NonReflectionTrace(med, g["m"], float(g["ext"]), float(g["trace_dt"]), ctx=ctx, info=True)
-    assert np.array_equal(out[:, 4:8], g["X_overshoot"])
+    assert np.array_equal(out[:, 4:8], g["X_overshoot"]) if exact else rel_err(out[:, 4:8], g["X_overshoot"]) <= RTOL
     assert np.array_equal(inf["status"], g["st_overshoot"]) and np.array_equal(inf["nsteps"], g["ns_overshoot"])
+    if not exact:
+        return
     # a11
     gm = golden("misfit_grid_n75.npz")
     r = ray_amd.misfit(g["m"], s, 0.2, ctx=ctx)
@@ -143,12 +161,17 @@ def test_theta_block_equals_whole(ctx):
 
 # ---- gridded shoot-to-exit at scale: bit-exact against the oracle from explicit states -------------
 @pytest.mark.parametrize("N,ns,nd,dt", [(75, 100, 100, 1e-2), (512, 64, 2048, 1e-2), (45, 50, 300, 5e-2)])
-def test_grid_shoot_vs_oracle(ctx, orc, N, ns, nd, dt):
+def test_grid_shoot_vs_oracle(ctx, orc, arith, N, ns, nd, dt):
     import ray_amd
     c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
-    tab = orc.GridTables(c, 1.5)
+    tab0 = orc.GridTables(c, 1.5)
+    tab = tab0.with_arith(arith)
     med = ray_amd.GridMedium(c, 1.5, ctx)
     ref, st, nst, _ = orc.scatter_relation(tab, ns, nd, dt, nthreads=16)
+    if arith:       # the fused flavour itself stays within tolerance of the as-written restatement
+        ref0, st0, nst0, _ = orc.scatter_relation(tab0, ns, nd, dt, nthreads=16)
+        assert np.array_equal(st, st0) and np.array_equal(nst, nst0)
+        assert rel_err(ref, ref0) <= RTOL            # measured ~1e-12
     # (1) library-generated boundary grid: device sin/cos vs libm -> tolerance
     m, info = ray_amd.ScatterRelation(med, None, ns, nd, dt, ctx=ctx, info=True)
     assert_rays(m, info, ref, st, nst)
@@ -160,11 +183,11 @@ def test_grid_shoot_vs_oracle(ctx, orc, N, ns, nd, dt):
     assert not np.any(st & orc.ST_OOB)
 
 
-def test_grid_obstacle_vs_oracle(ctx, orc):
+def test_grid_obstacle_vs_oracle(ctx, orc, arith):
     """a7 loop over a gridded medium (composition): bit-exact from explicit states."""
     import ray_amd
     c = orc.sinprod_grid(orc.OBSTACLE_DEMO, 129, 1.5)
-    tab = orc.GridTables(c, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
     med = ray_amd.GridMedium(c, 1.5, ctx)
     ref, st, nst, nrf = orc.scatter_relation(tab, 16, 256, 1e-2, obstacle_r0=0.3, time_unit=1, nthreads=8)
     m2 = np.asfortranarray(ref.copy())
@@ -177,12 +200,12 @@ def test_grid_obstacle_vs_oracle(ctx, orc):
 # ---- a8 / a9 at the shipped reconstruction sizes -------------------------------------------------------
 @pytest.mark.parametrize("N,ns,nd", [(75, 100, 100), (45, 50, 300)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_trace_vs_oracle_bit_exact(ctx, orc, N, ns, nd, mode):
+def test_trace_vs_oracle_bit_exact(ctx, orc, arith, N, ns, nd, mode):
     import ray_amd
     data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, nthreads=8)     # "measured" m
     # a perturbed model c0 (as inside the reconstruction loop): rays end away from the boundary
     c0 = np.asfortranarray(0.85 * orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) + 0.1)
-    tab = orc.GridTables(c0, 1.5)
+    tab = orc.GridTables(c0, 1.5, arith)
     X, st, nst = orc.trace_fixed_time(tab, data, 5e-2, mode, nthreads=8)
     med = ray_amd.GridMedium(c0, 1.5, ctx)
     if mode == 0:
@@ -195,12 +218,12 @@ def test_trace_vs_oracle_bit_exact(ctx, orc, N, ns, nd, mode):
     assert np.array_equal(got, X)
 
 
-def test_trace_cease_and_oob_flags(ctx, orc):
+def test_trace_cease_and_oob_flags(ctx, orc, arith):
     """rays that leave 1+2h are ceased (a9) / run off the grid and are clamped + flagged (a8)."""
     import ray_amd
     N = 45
     c0 = np.asfortranarray(np.full((N, N), 1.0))
-    tab = orc.GridTables(c0, 1.5)
+    tab = orc.GridTables(c0, 1.5, arith)
     data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, 10, 50, 1e-2, nthreads=4)
     data[:, 8] *= 3.0                                   # far too long: rays fly out of the disk
     med = ray_amd.GridMedium(c0, 1.5, ctx)
@@ -231,7 +254,7 @@ def test_misfit_vs_oracle(ctx, orc, num):
 
 
 # ---- size-independent properties at the BASELINE config-2 size (2048 x 2048 rays, 512^2 grid) --------
-def test_full_size_properties(ctx, orc):
+def test_full_size_properties(ctx, orc, arith):
     import ray_amd
     N, ns, nd, dt = 512, 2048, 2048, 1e-2
     med1 = ray_amd.GridMedium(np.ones((N, N), order="F"), 1.5, ctx)
@@ -266,7 +289,7 @@ def test_full_size_properties(ctx, orc):
     idx = np.arange(0, ns * nd, 4099)
     sub = np.asfortranarray(m[idx].copy())
     ref = np.asfortranarray(sub.copy())
-    tab = orc.GridTables(c, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
     st, nst, _ = orc.shoot(tab, ref, dt, nthreads=16)
     assert np.array_equal(ref, sub)
     assert np.array_equal(info["nsteps"][idx], nst) and np.array_equal(info["status"][idx], st)
