@@ -78,7 +78,8 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     double *p_lds = reinterpret_cast<double *>(ray_smem);
     for (int k = threadIdx.x; k < g.N; k += blockDim.x) p_lds[k] = g.p[k];
     const unsigned poff = ((unsigned)g.N * 8u + 15u) & ~15u;
-    const unsigned wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // wave-uniform by construction; readfirstlane tells the compiler so (LDS bases live in SGPRs)
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     a.wrec = poff + wave * (kRunSlots * 96);
     a.wcells = poff + nw * (kRunSlots * 96) + wave * (kRunSlots * 4);
     a.lane = threadIdx.x & 63;
