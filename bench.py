@@ -52,6 +52,19 @@ def cpu_baseline(seconds_target=12.0):
                       "reference's Julia CPU path, -O2 -ffp-contract=off, OpenMP over rays)"}
 
 
+def recorded_traffic():
+    """HBM bytes per launch of the shoot kernel from the newest committed PMC profile
+    (profiles/rN/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
+    as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so
+    this is the recorded figure of the same command, not a live one; None if no profile exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("traffic_bytes_per_launch"), d.get("l2_hit_rate")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +161,7 @@ def main():
         kern_s = cnt["kernel_ms"] * 1e-3 / max(cnt["launches"], 1)
         steps_per_launch = cnt["ray_steps"] / max(cnt["launches"], 1)
         achieved = F_STEP_GRID * steps_per_launch / kern_s / 1e12
+        traffic, l2_hit = recorded_traffic()
         out = {
             "metric": "fp64 RK4 ray-steps/sec", "value": ray_steps / elapsed, "unit": "ray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +176,8 @@ def main():
                        "parallelism": f"theta-block x{world}"},
             "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK, "traffic": traffic,
+                         "l2_hit_rate": l2_hit,
                          "kernel_ms": kern_s * 1e3, "ray_steps_per_launch": steps_per_launch,
                          "flop_per_ray_step": F_STEP_GRID,
                          "kernel_ray_steps_per_s": steps_per_launch / kern_s},
