@@ -84,11 +84,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal knobs (1-GPU box only): RAY_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # RAY_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised without N GPUs
+    if os.environ.get("RAY_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("RAY_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import ray_amd
     from ray_amd import device as rdev
