@@ -61,6 +61,8 @@ struct GridAcc {
     unsigned wrec;           // LDS byte offset of this wave's record slots
     unsigned wcells;         // LDS byte offset of this wave's cell-id slots
     unsigned lane;
+    unsigned role_run4[3];   // loader role slot s (shift 0,4,2): 4 * ((lane + shift) / 6) ...
+    unsigned role_poff[3];   // ... and 16 * ((lane + shift) % 6); see fetch_records()
 };
 
 __host__ __device__ inline size_t grid_lds_bytes(int N, int block)
@@ -83,6 +85,12 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     a.wrec = poff + wave * (kRunSlots * 96);
     a.wcells = poff + nw * (kRunSlots * 96) + wave * (kRunSlots * 4);
     a.lane = threadIdx.x & 63;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        const unsigned v = a.lane + (sl == 0 ? 0u : sl == 1 ? 4u : 2u), run = (v * 171u) >> 10;   // v / 6
+        a.role_run4[sl] = run * 4u;
+        a.role_poff[sl] = (v - run * 6u) * 16u;
+    }
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
     if (a.lane < (unsigned)kRunSlots) *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
     __syncthreads();
@@ -108,43 +116,64 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c)   
     return __umul24(a, b) + c;
 }
 
-__device__ __forceinline__ void load_piece(const char *rec, const GridAcc &a, unsigned lane, int t, unsigned npiece)
+// Loader roles.  In pass t lane l handles piece q = 64t + l: run q/6, 16-byte piece q%6.  Because
+// 64 = 6*10 + 4, q = 6*base_t + sh_t + l with sh_t = 4t mod 6 = 0,4,2,0,4,2 and base_t = 0,10,21,32,
+// 42,53: only three role patterns exist (slot t%3), the pass enters as a constant run offset.
+__device__ __forceinline__ constexpr unsigned pass_shift(int t) { return (4u * t) % 6u; }
+__device__ __forceinline__ constexpr unsigned pass_base(int t) { return (64u * t - (4u * t) % 6u) / 6u; }
+
+template <int T>
+__device__ __forceinline__ unsigned read_cell_of_pass(const GridAcc &a)
 {
-    const unsigned q = t * 64u + lane, run = (q * 171u) >> 10;               // run = q / 6 for q < 505
-    const unsigned c = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run * 4u);
-    if (q < npiece)
-        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, (q - run * 6u) * 16u)),
-                                         (lptr_t)(ray_smem + a.wrec + t * 1024u), 16, 0, 0);
+    return *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + a.role_run4[T % 3] + 4u * pass_base(T));
+}
+template <int T>
+__device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsigned c, unsigned npiece)
+{
+    if (a.lane + 64u * T < npiece)
+        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, a.role_poff[T % 3])),
+                                         (lptr_t)(ray_smem + a.wrec + T * 1024u), 16, 0, 0);
 }
 
 __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int cid, double2 out[6])
 {
+#ifdef RAY_ABLATE_NOFETCH
+    asm volatile("" :: "v"(cid));
+    out[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) out[k] = make_double2(0.0, 0.0);
+    asm volatile("" : "+v"(out[0].x), "+v"(out[0].y), "+v"(out[1].x), "+v"(out[1].y), "+v"(out[2].x), "+v"(out[2].y));
+    asm volatile("" : "+v"(out[3].x), "+v"(out[3].y), "+v"(out[4].x), "+v"(out[4].y), "+v"(out[5].x), "+v"(out[5].y));
+    return;
+#endif
     // left neighbour's cell (wave_shr:1; lane 0 keeps ~cid, i.e. is always a leader)
     const int left = __builtin_amdgcn_update_dpp(~cid, cid, 0x138, 0xf, 0xf, false);
     const bool leader = left != cid;
     const unsigned long long mask = __ballot(leader);
-    const unsigned npiece = 6u * (unsigned)__builtin_popcountll(mask);       // wave-uniform, >= 6
-    const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    const unsigned rank = before + (leader ? 1u : 0u) - 1u;                  // run index of this lane
+    const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    const unsigned npiece = 6u * (unsigned)(__builtin_popcount(mlo) + __builtin_popcount(mhi));   // uniform, >= 6
+    // run index of this lane = leaders at or below it, minus one = set bits of (mask >> 1) below it
+    // (bit 0 is always set)
+    const unsigned long long m1 = mask >> 1;
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
     if (leader) *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
     const char *rec = reinterpret_cast<const char *>(g.rec);
     // passes 0 and 1 (<= 21 runs, the common case): both cell-id reads first, then both DMA loads
-    const unsigned q1 = 64u + a.lane, run0 = (a.lane * 171u) >> 10, run1 = (q1 * 171u) >> 10;
-    unsigned c0 = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run0 * 4u);
-    unsigned c1 = *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + run1 * 4u);
+    unsigned c0 = read_cell_of_pass<0>(a), c1 = read_cell_of_pass<1>(a);
     asm volatile("" : "+v"(c0), "+v"(c1));                                   // keep the reads ahead of the masks
-    if (a.lane < npiece)
-        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c0, 96u, (a.lane - run0 * 6u) * 16u)),
-                                         (lptr_t)(ray_smem + a.wrec), 16, 0, 0);
-    if (q1 < npiece)
-        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c1, 96u, (q1 - run1 * 6u) * 16u)),
-                                         (lptr_t)(ray_smem + a.wrec + 1024u), 16, 0, 0);
+    dma_pass<0>(rec, a, c0, npiece);
+    dma_pass<1>(rec, a, c1, npiece);
     if (npiece > 128u) {                                                     // wide fans: up to 4 more passes
-        unsigned lane = a.lane;
-        asm volatile("" : "+v"(lane));                                       // recompute the roles here, do not
-#pragma unroll                                                               // hold them in registers all kernel
-        for (int t = 2; t < kPasses; ++t)
-            if (npiece > 64u * t) load_piece(rec, a, lane, t, npiece);
+        unsigned c2 = read_cell_of_pass<2>(a), c3 = read_cell_of_pass<3>(a);
+        asm volatile("" : "+v"(c2), "+v"(c3));
+        dma_pass<2>(rec, a, c2, npiece);
+        dma_pass<3>(rec, a, c3, npiece);
+        if (npiece > 256u) {
+            unsigned c4 = read_cell_of_pass<4>(a), c5 = read_cell_of_pass<5>(a);
+            asm volatile("" : "+v"(c4), "+v"(c5));
+            dma_pass<4>(rec, a, c4, npiece);
+            dma_pass<5>(rec, a, c5, npiece);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec));
