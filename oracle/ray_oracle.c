@@ -161,16 +161,17 @@ int orc_discrete_hamilton(const double X[4], const double *eval, const double *g
  * the compiler contract a*b+c into one fused multiply-add.  This flavour spells out one such
  * contraction explicitly (the one the HIP kernels use in RAY_ARITH_FUSED), so that the kernel
  * can be checked bit for bit; against the as-written flavour above it differs by rounding only.
- *   cell index  floor(fma(x, rh, nb)),  rh = 1/h, nb = -p[1]*rh
- *   dot         fma(dxdy, t3, fma(dy, t2, fma(dx, t1, t0)))
+ *   cell index  trunc(fma(x, rh, nb)),  rh = 1/h, nb = -p[1]*rh   (trunc == floor for q >= 0; the
+ *               reference's behaviour is undefined below the grid anyway: q in (-1,0) -> cell 1)
+ *   dot         fma(dx, fma(dy, t3, t1), fma(dy, t2, t0))
  *   tau         fma(py, py, px*px);  H[2:3] = (-g) * (c*tau)
  *   RK4         Y = fma(H, dt/2, X) / fma(H, dt, X);  acc = fma(2, H, acc);
  *               X += fma(acc + H4, dt*RN(1/6), X)                                              */
 static int cell_index_fused(double x, double rh, double nb, int N, int *oob)
 {
-    double q = floor(fma(x, rh, nb));
+    double q = trunc(fma(x, rh, nb));
     int I;
-    if (!(q >= 0.0)) { I = 1; *oob = 1; }
+    if (!(q > -1.0)) { I = 1; *oob = 1; }                 /* q <= -1 or NaN */
     else if (q > (double)(N - 3)) { I = N - 2; *oob = 1; }
     else I = (int)q + 1;
     return I;
@@ -178,9 +179,9 @@ static int cell_index_fused(double x, double rh, double nb, int N, int *oob)
 static double zdot_fused(double dx, double dy, double dxdy, const double *tab, int64_t base,
                          int64_t plane, int k0)
 {
-    return fma(dxdy, tab[base + (k0 + 3) * plane],
-               fma(dy, tab[base + (k0 + 2) * plane],
-                   fma(dx, tab[base + (k0 + 1) * plane], tab[base + (k0 + 0) * plane])));
+    (void)dxdy;
+    return fma(dx, fma(dy, tab[base + (k0 + 3) * plane], tab[base + (k0 + 1) * plane]),
+               fma(dy, tab[base + (k0 + 2) * plane], tab[base + (k0 + 0) * plane]));
 }
 int orc_discrete_hamilton_fused(const double X[4], const double *eval, const double *grad,
                                 const double *p, int N, double H[4])

@@ -196,9 +196,12 @@ enum Arith { kExact = 0, kFused = 1 };
 template <int AR>
 __device__ __forceinline__ int cell_of(double x, const GridDev &g, int &oob)
 {
-    const double q = (AR == kFused) ? __builtin_floor(__builtin_fma(x, g.rh, g.nb))
+    // kExact: floor of the correctly rounded quotient.  kFused: one fma, and the conversion's own
+    // truncation stands in for floor (equal for q >= 0; q in (-1,0) lands in cell 0 un-flagged,
+    // which the oracle's fused flavour defines the same way).
+    const double q = (AR == kFused) ? __builtin_fma(x, g.rh, g.nb)
                                     : __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
-    int iraw, i;                                 // v_cvt saturates; (int)q would be UB out of range
+    int iraw, i;                                 // v_cvt truncates and saturates; (int)q would be UB out of range
     asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
     oob |= (i != iraw);
@@ -218,18 +221,19 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
     double2 r[6];
     fetch_records(g, a, cid, r);
     const double dx = X[0] - pi_, dy = X[1] - pj_;
-    const double dxdy = dx * dy;
     if (AR == kFused) {
+        // t0 + t1 dx + t2 dy + t3 dx dy = fma(dx, fma(dy, t3, t1), fma(dy, t2, t0))
         const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
-        const double c = __builtin_fma(dxdy, r[1].y, __builtin_fma(dy, r[1].x, __builtin_fma(dx, r[0].y, r[0].x)));
-        const double gcX = __builtin_fma(dxdy, r[3].y, __builtin_fma(dy, r[3].x, __builtin_fma(dx, r[2].y, r[2].x)));
-        const double gcY = __builtin_fma(dxdy, r[5].y, __builtin_fma(dy, r[5].x, __builtin_fma(dx, r[4].y, r[4].x)));
+        const double c = __builtin_fma(dx, __builtin_fma(dy, r[1].y, r[0].y), __builtin_fma(dy, r[1].x, r[0].x));
+        const double gcX = __builtin_fma(dx, __builtin_fma(dy, r[3].y, r[2].y), __builtin_fma(dy, r[3].x, r[2].x));
+        const double gcY = __builtin_fma(dx, __builtin_fma(dy, r[5].y, r[4].y), __builtin_fma(dy, r[5].x, r[4].x));
         const double c2 = c * c, w = c * tau;
         H[0] = c2 * X[2];
         H[1] = c2 * X[3];
         H[2] = (-gcX) * w;
         H[3] = (-gcY) * w;
     } else {
+        const double dxdy = dx * dy;
         const double tau = X[2] * X[2] + X[3] * X[3];
         const double c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
         const double gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
