@@ -256,6 +256,9 @@ def shoot_states(c, m, dt, ob=None, time_unit=TIME_SECONDS, *, ctx=None, max_ste
 
 def _trace(c, m, ext, dt, mode, ctx, info):
     ctx = ctx or default_context()
+    if isinstance(c, SinProd):
+        raise RayError("fixed-time tracing is defined on gridded media only (NonObstacle.jl:189, "
+                       "Obstacle.jl:275 take c::Matrix)")
     med = c if isinstance(c, GridMedium) else GridMedium(c, ext, ctx)
     m = np.asfortranarray(m, dtype=np.float64)
     num = m.shape[0]

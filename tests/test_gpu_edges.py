@@ -1,0 +1,188 @@
+"""GPU edge cases through the C ABI: ragged / tiny / strided shapes, non-default direction ranges,
+caps and flags, garbage inputs, the 1024^2 grid, context reuse.  Same bars as test_gpu_parity.py."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def rel_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) if a.size else 0.0
+
+
+@pytest.fixture(params=[0, 1], ids=["exact", "fused"])
+def arith(ctx, request):
+    import ray_amd
+    ctx.set_arith(request.param)
+    yield request.param
+    ctx.set_arith(ray_amd.ARITH_FUSED)
+
+
+@pytest.mark.parametrize("ns,nd", [(1, 1), (1, 63), (3, 65), (5, 129), (2, 64)])
+def test_ragged_shapes_grid(ctx, orc, arith, ns, nd):
+    import ray_amd
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 61, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ref, st, nst, _ = orc.scatter_relation(tab, ns, nd, 1e-2)
+    m, info = ray_amd.ScatterRelation(med, None, ns, nd, 1e-2, ctx=ctx, info=True)
+    assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
+    assert rel_err(m, ref) <= RTOL
+    got = np.asfortranarray(ref.copy())
+    got[:, 4:] = 0
+    ray_amd.shoot_states(med, got, 1e-2, ctx=ctx)
+    assert np.array_equal(got, ref)
+
+
+def test_direction_range_and_context_reuse(ctx, orc):
+    """dir = (0.3, 2.0) (NonObstacle.jl:56 takes any range) and back-to-back calls with different
+    grids on one context (the cached boundary tables must be rebuilt)."""
+    import ray_amd
+    sp = ray_amd.SinProd.smooth_demo()
+    for ns, nd, lo, hi in [(9, 70, 0.3, 2.0), (9, 70, 0.0, math.pi), (4, 30, 1.0, 1.2), (9, 70, 0.3, 2.0)]:
+        ref, st, nst, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, dir_lo=lo, dir_hi=hi)
+        m, info = ray_amd.ScatterRelation(sp, None, ns, nd, 1e-2, (lo, hi), ctx=ctx, info=True)
+        assert np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
+        assert rel_err(m, ref) <= RTOL
+
+
+def test_strided_host_arrays(ctx, orc, arith):
+    """leading dimension larger than the row count (a view into a bigger Julia/NumPy array)."""
+    from ray_amd import _lib
+    import ray_amd
+    lib = _lib.load()
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 75, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ns, nd, num, ld = 6, 50, 300, 417
+    ref, st, nst, _ = orc.scatter_relation(tab, ns, nd, 1e-2)
+    big = np.full((ld, 9), -3.0, order="F")
+    big[:num, 0:4] = ref[:, 0:4]
+    stat = np.zeros(num, dtype=np.int32)
+    rc = lib.ray_shoot_states(ctx.handle, med.handle, None, 1e-2, 0, 0, big.ctypes.data, num, ld,
+                              stat.ctypes.data, None, None)
+    assert rc == 0
+    assert np.array_equal(big[:num], ref) and np.all(big[num:] == -3.0) and np.array_equal(stat, st)
+    X = np.full((ld, 4), -5.0, order="F")
+    rc = lib.ray_trace_fixed_time(ctx.handle, med.handle, big.ctypes.data, num, ld, 5e-2, 0, X.ctypes.data, ld, None, None)
+    assert rc == 0
+    Xr, _, _ = orc.trace_fixed_time(tab, ref, 5e-2, 0)
+    assert np.array_equal(X[:num], Xr) and np.all(X[num:] == -5.0)
+    obs = big.copy(order="F")
+    obs[:num, 4:8] = X[:num]
+    out = np.zeros(2)
+    assert lib.ray_misfit(ctx.handle, big.ctypes.data, obs.ctypes.data, num, ld, out.ctypes.data, None, 0.2, None) == 0
+    o2 = np.asfortranarray(ref.copy())
+    o2[:, 4:8] = Xr
+    _, want, _ = orc.misfit(ref, o2, 0.2)
+    assert np.allclose(out, want, rtol=1e-12, atol=0)
+
+
+def test_step_cap_and_bad_arguments(ctx, orc):
+    import ray_amd
+    from ray_amd import _lib
+    lib = _lib.load()
+    sp = ray_amd.SinProd.smooth_demo()
+    ref, st, nst, _ = orc.scatter_relation(orc.SMOOTH_DEMO, 3, 40, 1e-2, max_steps=30)
+    m, info = ray_amd.ScatterRelation(sp, None, 3, 40, 1e-2, ctx=ctx, max_steps=30, info=True)
+    assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
+    assert np.any(st == orc.ST_STEP_CAP) and np.any(st == orc.ST_EXITED)
+    assert rel_err(m, ref) <= RTOL
+    # argument errors: negative code + message, nothing written
+    prm = _lib.ShootParams(4, 4, 0, 5, 0.0, 3.0, 1e-2, 0, 0)          # src_end > ns
+    buf = np.zeros((16, 9), order="F")
+    med = sp._medium(ctx)
+    assert lib.ray_shoot_to_exit(ctx.handle, med.handle, None, C.byref(prm), buf.ctypes.data, 16, None, None, None) == -1
+    assert b"src_begin" in lib.ray_last_error()
+    prm = _lib.ShootParams(4, 4, 0, 4, 0.0, 3.0, -1.0, 0, 0)         # dt < 0
+    assert lib.ray_shoot_to_exit(ctx.handle, med.handle, None, C.byref(prm), buf.ctypes.data, 16, None, None, None) == -1
+    prm = _lib.ShootParams(4, 4, 0, 4, 0.0, 3.0, 1e-2, 0, 0)
+    assert lib.ray_shoot_to_exit(ctx.handle, med.handle, None, C.byref(prm), buf.ctypes.data, 3, None, None, None) == -1   # ld < rows
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.NonReflectionTrace(sp, buf, 1.5, 1e-2, ctx=ctx)       # fixed-time trace needs a gridded medium
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.GridMedium(np.ones((3, 3)), 1.5, ctx)                 # N < 4
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.ScatterRelation(lambda x, y: 1.0, None, 4, 4, 1e-2, ctx=ctx)   # closures cannot cross the ABI
+
+
+def test_garbage_states_are_flagged_like_the_oracle(ctx, orc, arith):
+    import ray_amd
+    N = 45
+    c0 = np.asfortranarray(np.full((N, N), 1.0))
+    tab = orc.GridTables(c0, 1.5, arith)
+    med = ray_amd.GridMedium(c0, 1.5, ctx)
+    rows = np.asfortranarray(np.zeros((70, 9)))
+    rows[:, 2] = 1.0
+    rows[:, 8] = 0.3
+    rows[1, 0] = np.nan            # NaN position
+    rows[2, 0] = 1e300             # absurd position
+    rows[3, 0] = -1.49             # inside the first cell column: valid but at the grad-less edge
+    rows[4, 0] = -1.6              # left of the grid
+    rows[5, 0], rows[5, 2] = 1.45, 1.0   # leaves the grid to the right
+    rows[6, 8] = 0.0               # T = 0: no step
+    rows[7, 8] = -1.0              # T < 0: no step
+    rows[8, 8] = 1e-9              # one tiny shortened step
+    for mode in (0, 1):
+        X, st, nst = orc.trace_fixed_time(tab, rows, 5e-2, mode)
+        Xg, inf = ray_amd._trace(med, rows, 1.5, 5e-2, mode, ctx, True)
+        assert np.array_equal(inf["status"], st), mode
+        assert np.array_equal(inf["nsteps"], nst), mode
+        ok = np.isfinite(X).all(axis=1) & (np.abs(X) < 1e100).all(axis=1)
+        assert np.array_equal(Xg[ok], X[ok])
+        assert st[1] & orc.ST_OOB and st[2] & orc.ST_OOB and st[4] & orc.ST_OOB and nst[6] == 0 and nst[7] == 0
+
+
+def test_grid_1024(ctx, orc, arith):
+    """BASELINE config 5's grid size: tables and a small sweep, bit-exact."""
+    import ray_amd
+    N = 1024
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    if arith == 0:
+        ev, gr, p = med.tables()
+        assert np.array_equal(p, tab.p) and np.array_equal(ev, tab.eval) and np.array_equal(gr, tab.grad)
+    ref, st, nst, _ = orc.scatter_relation(tab, 8, 512, 1e-2, nthreads=16)
+    got = np.asfortranarray(ref.copy())
+    got[:, 4:] = 0
+    info = ray_amd.shoot_states(med, got, 1e-2, ctx=ctx)
+    assert np.array_equal(got, ref) and np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
+    # h/2 step (SURVEY.md section 8d secondary point): many steps per cell
+    dt = (3.0 / (N - 1)) / 2
+    ref, st, nst, _ = orc.scatter_relation(tab, 2, 256, dt, nthreads=16)
+    got = np.asfortranarray(ref.copy())
+    got[:, 4:] = 0
+    info = ray_amd.shoot_states(med, got, dt, ctx=ctx)
+    assert np.array_equal(got, ref) and np.array_equal(info["nsteps"], nst)
+
+
+def test_wide_fan_many_runs(ctx, orc, arith):
+    """few directions over the whole half-circle: lanes of one wave spread over > 21 and > 42 cell
+    runs, exercising every pass of the cooperative record fetch."""
+    import ray_amd
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, 512, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    for ns, nd in [(4, 64), (2, 48), (3, 200)]:
+        ref, st, nst, _ = orc.scatter_relation(tab, ns, nd, 1e-2, nthreads=8)
+        got = np.asfortranarray(ref.copy())
+        got[:, 4:] = 0
+        info = ray_amd.shoot_states(med, got, 1e-2, ctx=ctx)
+        assert np.array_equal(got, ref) and np.array_equal(info["nsteps"], nst)
+    # random, incoherent rows: every lane in its own cell
+    rng = np.random.default_rng(7)
+    ang = rng.uniform(0, 2 * math.pi, 4096)
+    rr = rng.uniform(0, 0.9, 4096)
+    dirs = rng.uniform(0, 2 * math.pi, 4096)
+    rows = np.asfortranarray(np.zeros((4096, 9)))
+    rows[:, 0], rows[:, 1] = rr * np.cos(ang), rr * np.sin(ang)
+    rows[:, 2], rows[:, 3] = np.cos(dirs), np.sin(dirs)
+    ref = np.asfortranarray(rows.copy())
+    st, nst, _ = orc.shoot(tab, ref, 1e-2, nthreads=8)
+    info = ray_amd.shoot_states(med, rows, 1e-2, ctx=ctx)
+    assert np.array_equal(rows, ref) and np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
