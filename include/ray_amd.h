@@ -151,6 +151,27 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
                              int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
                              int32_t *status_dev, int32_t *nsteps_dev);
 
+/* ---- complete ScatterForwardOperator (NonObstacle.jl:189-243; SURVEY.md section 8f NEXT-1) -----------
+ * Per ray: the traced end state X (= the `s` output, identical to RAY_TRACE_SHORTEN_CEASE), the
+ * Jacobian rho (NonObstacle.jl:149,166-172; rho_host: num x 16 row-major, may be NULL) and its
+ * 4 x N^2 block rho*Phi of the Frechet matrix M (NonObstacle.jl:158-159,174-184; dV :107-139,
+ * DiscreteHamilton with Hessian :6-28, hess table :212-218).
+ * The reference assembles M densely (4num x N^2 SharedArray) and calls sparse()/droptol! (:242).
+ * Here the un-merged stencil contributions are returned as COO triplets, ray by ray:
+ *   rows[k] = 4*ray + component (0-based), cols[k] = i + j*N (0-based node, first index x),
+ * duplicates NOT summed: feed them to the caller's sparse constructor (Julia sparse(I,J,V,m,n),
+ * scipy coo_matrix(...).tocsr()), which sums duplicates exactly like the reference's sparse() at
+ * :137, then apply droptol (1e-12, :242).  Parity is by tolerance (the reference goes through
+ * LAPACK inv / BLAS gemm).                                                                      */
+typedef struct ray_frechet ray_frechet;
+int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld,
+                         double dt, double *X_host, int64_t ldx, double *rho_host, int32_t *status,
+                         int32_t *nsteps, ray_frechet **out);
+int ray_frechet_count(ray_frechet *f, int64_t *n_triplets);
+int ray_frechet_export_coo(ray_frechet *f, int64_t *rows, int64_t *cols, double *vals, int64_t cap,
+                           int64_t *n_written);
+int ray_frechet_destroy(ray_frechet *f);
+
 /* ---- misfit (NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252) ------------------
  * out[0] = sum_r,k (m[r,4+k]-obs[r,4+k])^2, out[1] = sum_r,k m[r,4+k]^2  (objective =
  * sqrt(out[0]/out[1])); mask[r] = |m[r,5:8]-obs[r,5:8]| / |m[r,5:8]| < perc_thresh;

@@ -86,6 +86,14 @@ class GridTables:
         self.grad = np.zeros((N - 2, N - 2, 8), dtype=np.float64, order="F")
         lib().orc_build_tables(_dp(c), C.c_int(N), C.c_double(ext), _dp(self.eval), _dp(self.grad))
 
+    def hess(self):
+        """hess (N-3,N-3,12), NonObstacle.jl:212-218 (built on first use)."""
+        if getattr(self, "_hess", None) is None:
+            N = self.N
+            self._hess = np.zeros((N - 3, N - 3, 12), dtype=np.float64, order="F")
+            lib().orc_build_hess(_dp(self.grad), C.c_int(N), C.c_double(self.ext), _dp(self._hess))
+        return self._hess
+
     def medium(self):
         m = Medium()
         m.kind = 1
@@ -161,6 +169,24 @@ def trace_fixed_time(tab, m_in, dt, mode, nthreads=1):
                                C.c_int64(num), _dp(X), C.c_int64(num), _dp(st), _dp(ns_),
                                C.c_int(nthreads))
     return X, st, ns_
+
+
+def forward_operator(tab, m_in, dt, dense=True, nthreads=1):
+    """Complete ScatterForwardOperator (NonObstacle.jl:189-243): returns (X (num,4), rho (num,4,4),
+    M_dense ((4num, N^2), Fortran) or None, status, nsteps)."""
+    assert m_in.flags.f_contiguous and m_in.shape[1] == 9
+    num, N = m_in.shape[0], tab.N
+    X = np.zeros((num, 4), dtype=np.float64, order="F")
+    rho = np.zeros((num, 4, 4), dtype=np.float64)
+    M = np.zeros((4 * num, N * N), dtype=np.float64, order="F") if dense else None
+    st = np.zeros(num, dtype=np.int32)
+    ns_ = np.zeros(num, dtype=np.int32)
+    f = lib().orc_forward_operator
+    f.restype = None
+    f(_dp(tab.eval), _dp(tab.grad), _dp(tab.hess()), _dp(tab.p), C.c_int(N), C.c_double(dt), C.c_int(tab.arith),
+      _dp(m_in), C.c_int64(num), C.c_int64(num), _dp(X), C.c_int64(num), _dp(rho),
+      _dp(M) if dense else None, _dp(st), _dp(ns_), C.c_int(nthreads))
+    return X, rho, M, st, ns_
 
 
 def misfit(m, obs, thresh=0.2):

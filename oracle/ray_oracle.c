@@ -478,3 +478,264 @@ void orc_misfit(const double *m, const double *obs, int64_t num, int64_t ld, dou
     out[0] = sm;
     out[1] = st;
 }
+
+
+/* ==========================================================================================
+ * NEXT-1: Jacobian rho and Frechet matrix M of ScatterForwardOperator.
+ * NonObstacle.jl:6-28 (DiscreteHamilton with Hessian), :107-139 (dV), :141-187 (ChunkProcessing!),
+ * :212-218 (hess table), :242 (droptol).
+ * The reference goes through LAPACK `inv` and BLAS gemm here, so no restatement can be bit-exact
+ * to it; operation order below is the natural one (k ascending) and parity is by tolerance.
+ * ======================================================================================== */
+
+/* hess (N-3,N-3,12) column-major; entries outside I,J in 3..N-3 are never written -> zero.
+ * NonObstacle.jl:212-218 */
+void orc_build_hess(const double *grad, int N, double ext, double *hess)
+{
+    const int64_t n2 = N - 2, n3 = N - 3;
+    double dx = 2 * ext / (N - 1);
+    memset(hess, 0, sizeof(double) * (size_t)(n3 * n3 * 12));
+#define GR(I, J, k) grad[((I) - 1) + ((J) - 1) * n2 + (int64_t)(k) * n2 * n2]
+    for (int I = 3; I <= N - 3; ++I)
+        for (int J = 3; J <= N - 3; ++J)
+            for (int k = 0; k < 4; ++k) {
+                hess[(I - 1) + (J - 1) * n3 + (int64_t)k * n3 * n3] = (GR(I + 1, J, k) - GR(I - 1, J, k)) / (2 * dx);
+                hess[(I - 1) + (J - 1) * n3 + (int64_t)(k + 4) * n3 * n3] = (GR(I, J + 1, k) - GR(I, J - 1, k)) / (2 * dx);
+                hess[(I - 1) + (J - 1) * n3 + (int64_t)(k + 8) * n3 * n3] = (GR(I, J + 1, k + 4) - GR(I, J - 1, k + 4)) / (2 * dx);
+            }
+#undef GR
+}
+
+typedef struct {            /* everything one table look-up yields at a point */
+    int I, J, oob;
+    double dx, dy, c, gcX, gcY, tau;
+} orc_point;
+
+static void point_eval(const double X[4], const double *eval, const double *grad, const double *p, int N,
+                       int arith, orc_point *q)
+{
+    const int64_t n1 = N - 1, n2 = N - 2;
+    double h = p[1] - p[0];
+    q->oob = 0;
+    if (arith) {
+        double rh = 1.0 / h, nb = -p[0] * rh;
+        q->I = cell_index_fused(X[0], rh, nb, N, &q->oob);
+        q->J = cell_index_fused(X[1], rh, nb, N, &q->oob);
+    } else {
+        q->I = cell_index(X[0], p[0], h, N, &q->oob);
+        q->J = cell_index(X[1], p[0], h, N, &q->oob);
+    }
+    q->dx = X[0] - p[q->I - 1];
+    q->dy = X[1] - p[q->J - 1];
+    double dxdy = q->dx * q->dy;
+    int64_t be = (q->I - 1) + (q->J - 1) * n1, bg = (q->I - 1) + (q->J - 1) * n2;
+    if (arith) {
+        q->tau = fma(X[3], X[3], X[2] * X[2]);
+        q->c = zdot_fused(q->dx, q->dy, dxdy, eval, be, n1 * n1, 0);
+        q->gcX = zdot_fused(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 0);
+        q->gcY = zdot_fused(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 4);
+    } else {
+        q->tau = X[2] * X[2] + X[3] * X[3];
+        q->c = zdot(q->dx, q->dy, dxdy, eval, be, n1 * n1, 0);
+        q->gcX = zdot(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 0);
+        q->gcY = zdot(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 4);
+    }
+}
+
+/* a3: DiscreteHamilton with Hessian: H and Jm = dH/dX (row-major 4x4).  NonObstacle.jl:6-28.
+ * H is the value of the chosen arithmetic flavour (so the X trajectory equals orc_trace_fixed_time's).
+ * hess look-ups outside I,J <= N-3 are undefined in the reference: clamped + flagged here.          */
+static int hamilton_jac(const double X[4], const double *eval, const double *grad, const double *hess,
+                        const double *p, int N, int arith, double H[4], double Jm[16])
+{
+    orc_point q;
+    point_eval(X, eval, grad, p, N, arith, &q);
+    int oob = q.oob;
+    const int64_t n3 = N - 3;
+    int Ih = q.I, Jh = q.J;
+    if (Ih > N - 3) { Ih = N - 3; oob = 1; }
+    if (Jh > N - 3) { Jh = N - 3; oob = 1; }
+    double dxdy = q.dx * q.dy;
+    int64_t bh = (Ih - 1) + (Jh - 1) * n3;
+    double hXX = zdot(q.dx, q.dy, dxdy, hess, bh, n3 * n3, 0);
+    double hXY = zdot(q.dx, q.dy, dxdy, hess, bh, n3 * n3, 4);
+    double hYY = zdot(q.dx, q.dy, dxdy, hess, bh, n3 * n3, 8);
+    double c = q.c, tau = q.tau, g[2] = {q.gcX, q.gcY}, hs[2][2] = {{hXX, hXY}, {hXY, hYY}};
+    double c2 = c * c;
+    if (arith) {
+        double w = c * tau;
+        H[0] = c2 * X[2]; H[1] = c2 * X[3]; H[2] = (-g[0]) * w; H[3] = (-g[1]) * w;
+    } else {
+        H[0] = c2 * X[2]; H[1] = c2 * X[3]; H[2] = ((-g[0]) * c) * tau; H[3] = ((-g[1]) * c) * tau;
+    }
+    /* M = [2*c*X[3:4]*g'  c^2*eye(2); -(c*h + g*g')*tau  -2*c*g*X[3:4]']    NonObstacle.jl:25 */
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            Jm[a * 4 + b] = ((2 * c) * X[2 + a]) * g[b];
+            Jm[a * 4 + 2 + b] = (a == b) ? c2 : 0.0;
+            Jm[(2 + a) * 4 + b] = (-(c * hs[a][b] + g[a] * g[b])) * tau;
+            Jm[(2 + a) * 4 + 2 + b] = ((-2 * c) * g[a]) * X[2 + b];
+        }
+    return oob;
+}
+
+/* dV: 24 entries (row 0..3, 1-based linear node index, value).  NonObstacle.jl:107-139.
+ * Node indices outside 1..N (I-1 < 1 or I+2 > N, same for J) would make the reference's sparse()
+ * throw: such entries are dropped and flagged.                                                    */
+static int dV(const double X[4], const double *eval, const double *grad, const double *p, int N, int arith,
+              int rows[24], int64_t cols[24], double vals[24])
+{
+    orc_point q;
+    point_eval(X, eval, grad, p, N, arith, &q);
+    int oob = q.oob;
+    double h = p[1] - p[0];
+    double u = q.dx / h, v = q.dy / h;
+    double phi[4] = {(1 - u) * (1 - v), u * (1 - v), (1 - u) * v, u * v};
+    double psi[4] = {u * (1 - v), -(1 - u) * (1 - v), u * v, -(1 - u) * v};
+    double gam[4] = {(1 - u) * v, u * v, -(1 - u) * (1 - v), -u * (1 - v)};
+    double c = q.c, tau = q.tau;
+    int I = q.I, J = q.J;
+    int ci[24] = {I, I + 1, I, I + 1, I, I + 1, I, I + 1, I, I + 1, I, I + 1, I + 2, I - 1, I + 2, I - 1,
+                  I, I + 1, I, I + 1, I, I + 1, I, I + 1};
+    int cj[24] = {J, J, J + 1, J + 1, J, J, J + 1, J + 1, J, J, J + 1, J + 1, J, J, J + 1, J + 1,
+                  J, J, J + 1, J + 1, J + 2, J + 2, J - 1, J - 1};
+    for (int k = 0; k < 4; ++k) {
+        rows[k] = 0;      vals[k] = 2 * c * X[2] * phi[k];
+        rows[4 + k] = 1;  vals[4 + k] = 2 * c * X[3] * phi[k];
+        rows[8 + k] = 2;  vals[8 + k] = -tau * q.gcX * phi[k] + c * tau * psi[k] / (2 * h);
+        rows[12 + k] = 2; vals[12 + k] = -c * tau * psi[k] / (2 * h);
+        rows[16 + k] = 3; vals[16 + k] = -tau * q.gcY * phi[k] + c * tau * gam[k] / (2 * h);
+        rows[20 + k] = 3; vals[20 + k] = -c * tau * gam[k] / (2 * h);
+    }
+    for (int k = 0; k < 24; ++k) {
+        if (ci[k] < 1 || ci[k] > N || cj[k] < 1 || cj[k] > N) { cols[k] = -1; oob = 1; }
+        else cols[k] = (int64_t)(ci[k] - 1) + (int64_t)(cj[k] - 1) * N;        /* 0-based */
+    }
+    return oob;
+}
+
+static void mat4_mul(const double A[16], const double B[16], double C[16])
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s = s + A[i * 4 + k] * B[k * 4 + j];
+            C[i * 4 + j] = s;
+        }
+}
+
+/* inv(rho): Gauss-Jordan with partial pivoting (the reference calls LAPACK getrf/getri) */
+static void mat4_inv(const double A[16], double Inv[16])
+{
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = A[i * 4 + j]; a[i][4 + j] = (i == j); }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (piv != col) for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+        double d = a[col][col];
+        for (int j = 0; j < 8; ++j) a[col][j] = a[col][j] / d;
+        for (int r = 0; r < 4; ++r) if (r != col) {
+            double f = a[r][col];
+            for (int j = 0; j < 8; ++j) a[r][j] = a[r][j] - f * a[col][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Inv[i * 4 + j] = a[i][4 + j];
+}
+
+/* Phi += inv(rho) * dV(X) * w   (w = dt/2 or T-t)                 NonObstacle.jl:158-159,174-175,178-179 */
+static int accumulate(double *Phi /* 4 x N^2, column-major (4 rows fastest) */, const double rho[16],
+                      const double X[4], const double *eval, const double *grad, const double *p, int N,
+                      int arith, double w, int halve)
+{
+    int rows[24]; int64_t cols[24]; double vals[24], inv[16];
+    int oob = dV(X, eval, grad, p, N, arith, rows, cols, vals);
+    mat4_inv(rho, inv);
+    for (int k = 0; k < 24; ++k) {
+        if (cols[k] < 0) continue;
+        for (int i = 0; i < 4; ++i) {
+            double th = inv[i * 4 + rows[k]] * vals[k] * w;
+            if (halve) th = th / 2;
+            Phi[i + 4 * cols[k]] += th;
+        }
+    }
+    return oob;
+}
+
+/* ScatterForwardOperator, complete (NonObstacle.jl:141-187, 189-243): for each ray the traced end
+ * state X (num,4), the final Jacobian rho (num,16 row-major) and the 4 x N^2 block rho*Phi of M,
+ * written DENSE into M_dense ((4*num) x N^2, column-major, leading dimension 4*num) like the
+ * reference's SharedArray M before sparse()/droptol!.  Meant for small N / few rays (tests).   */
+void orc_forward_operator(const double *eval, const double *grad, const double *hess, const double *p, int N,
+                          double timeStep, int arith, const double *m_in, int64_t num, int64_t ld,
+                          double *X_out, int64_t ldx, double *rho_out, double *M_dense,
+                          int32_t *status, int32_t *nsteps, int nthreads)
+{
+    (void)nthreads;
+    const double cease_r = 1 + 2 * (p[1] - p[0]);
+    const int64_t NN = (int64_t)N * N;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < num; ++i) {
+        double X[4], rho[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        double *Phi = (double *)calloc((size_t)(4 * NN), sizeof(double));
+        for (int k = 0; k < 4; ++k) X[k] = m_in[i + k * ld];
+        const double Ti = m_in[i + 8 * ld];
+        double t = 0, dt = timeStep;
+        int st = 0, steps = 0;
+        while (t < Ti) {
+            if (steps >= ORC_FIXED_STEP_CAP) { st |= ORC_ST_STEP_CAP; break; }
+            if ((t + dt) > Ti) dt = Ti - t;
+            t = t + dt;
+            if (accumulate(Phi, rho, X, eval, grad, p, N, arith, dt, 1)) st |= ORC_ST_OOB;      /* :158-159 */
+            double k1[4], k2[4], k3[4], k4[4], t1[16], t2[16], t3[16], t4[16], Y[4];
+            double v1[16], v2[16], v3[16], v4[16], R[16];
+            int o = 0;
+            /* the X stages follow the chosen flavour exactly as orc_trace_fixed_time does */
+            o |= hamilton_jac(X, eval, grad, hess, p, N, arith, k1, t1);
+            for (int k = 0; k < 4; ++k) Y[k] = arith ? fma(k1[k], 0.5 * dt, X[k]) : X[k] + k1[k] / 2 * dt;
+            o |= hamilton_jac(Y, eval, grad, hess, p, N, arith, k2, t2);
+            for (int k = 0; k < 4; ++k) Y[k] = arith ? fma(k2[k], 0.5 * dt, X[k]) : X[k] + k2[k] / 2 * dt;
+            o |= hamilton_jac(Y, eval, grad, hess, p, N, arith, k3, t3);
+            for (int k = 0; k < 4; ++k) Y[k] = arith ? fma(k3[k], dt, X[k]) : X[k] + k3[k] * dt;
+            o |= hamilton_jac(Y, eval, grad, hess, p, N, arith, k4, t4);
+            if (o) st |= ORC_ST_OOB;
+            mat4_mul(t1, rho, v1);                                                           /* :166 */
+            for (int k = 0; k < 16; ++k) R[k] = rho[k] + v1[k] * dt / 2;
+            mat4_mul(t2, R, v2);                                                             /* :167 */
+            for (int k = 0; k < 16; ++k) R[k] = rho[k] + v2[k] * dt / 2;
+            mat4_mul(t3, R, v3);                                                             /* :168 */
+            for (int k = 0; k < 16; ++k) R[k] = rho[k] + v3[k] * dt;
+            mat4_mul(t4, R, v4);                                                             /* :169 */
+            if (arith) {
+                const double dt6 = dt * 0.16666666666666666;
+                for (int k = 0; k < 4; ++k) {
+                    double acc = fma(2.0, k3[k], fma(2.0, k2[k], k1[k]));
+                    X[k] = fma(acc + k4[k], dt6, X[k]);
+                }
+            } else {
+                for (int k = 0; k < 4; ++k) X[k] = X[k] + (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]) * dt / 6.0;   /* :171 */
+            }
+            for (int k = 0; k < 16; ++k) rho[k] = rho[k] + (((v1[k] + 2 * v2[k]) + 2 * v3[k]) + v4[k]) * dt / 6.0;   /* :172 */
+            ++steps;
+            if (accumulate(Phi, rho, X, eval, grad, p, N, arith, dt, 1)) st |= ORC_ST_OOB;      /* :174-175 */
+            if (norm2(X[0], X[1]) > cease_r) {                                                /* :177-181 */
+                if (accumulate(Phi, rho, X, eval, grad, p, N, arith, Ti - t, 0)) st |= ORC_ST_OOB;
+                t = t + (Ti - t);
+                st |= ORC_ST_CEASED;
+            }
+        }
+        for (int k = 0; k < 4; ++k) X_out[i + k * ldx] = X[k];
+        if (rho_out) for (int k = 0; k < 16; ++k) rho_out[i * 16 + k] = rho[k];
+        if (M_dense)                                                                          /* :184 */
+            for (int64_t col = 0; col < NN; ++col)
+                for (int r = 0; r < 4; ++r) {
+                    double s = 0;
+                    for (int k = 0; k < 4; ++k) s = s + rho[r * 4 + k] * Phi[k + 4 * col];
+                    M_dense[(4 * i + r) + col * (4 * num)] = s;
+                }
+        free(Phi);
+        if (status) status[i] = st;
+        if (nsteps) nsteps[i] = steps;
+    }
+}

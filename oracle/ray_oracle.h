@@ -78,6 +78,13 @@ void   orc_trace_fixed_time(const double *eval, const double *grad, const double
                             double *X_out, int64_t ldx, int32_t *status, int32_t *nsteps,
                             int nthreads);
 
+/* NEXT-1: hess table, and the complete ScatterForwardOperator (X, rho, dense M) -- ray_oracle.c */
+void   orc_build_hess(const double *grad, int N, double ext, double *hess);
+void   orc_forward_operator(const double *eval, const double *grad, const double *hess, const double *p, int N,
+                            double timeStep, int arith, const double *m_in, int64_t num, int64_t ld,
+                            double *X_out, int64_t ldx, double *rho_out, double *M_dense,
+                            int32_t *status, int32_t *nsteps, int nthreads);
+
 /* a11 */
 void   orc_misfit(const double *m, const double *obs, int64_t num, int64_t ld,
                   double *mismatch /* 4*num or NULL */, double out[2] /* sum mismatch^2, sum target^2 */,

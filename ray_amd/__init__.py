@@ -271,16 +271,57 @@ def _trace(c, m, ext, dt, mode, ctx, info):
     return X, {"status": st, "nsteps": nst}
 
 
-def ScatterForwardOperator(c, m, ext, dt, *, ctx=None, info=False):
-    """NonObstacle.jl:189-243, ray-trajectory part: returns (M, s) with s[:,1:4], s[:,9] copied
-    from m (:196) and s[:,5:8] the traced end states (:185).  M -- the Frechet matrix -- is the
-    NEXT-1 row of SURVEY.md section 8f and is returned as None in this round."""
-    X, inf = _trace(c, m, ext, dt, TRACE_SHORTEN_CEASE, ctx, info)
-    s = np.zeros((m.shape[0], 9), dtype=np.float64, order="F")
-    s[:, 0:4] = m[:, 0:4]
-    s[:, 8] = m[:, 8]
+def forward_operator_coo(c, m, ext, dt, *, ctx=None):
+    """The complete ChunkProcessing! pass (NonObstacle.jl:146-185) on the GPU: returns
+    (rows, cols, vals, X, rho, info) -- the un-merged COO contributions of the Frechet matrix
+    (0-based; rows = 4*ray + component, cols = i + j*N), the traced end states X (num, 4), the
+    Jacobians rho (num, 4, 4) and the per-ray status / step counts."""
+    ctx = ctx or default_context()
+    if isinstance(c, SinProd):
+        raise RayError("ScatterForwardOperator is defined on gridded media only (NonObstacle.jl:189)")
+    med = c if isinstance(c, GridMedium) else GridMedium(c, ext, ctx)
+    m = np.asfortranarray(m, dtype=np.float64)
+    num = m.shape[0]
+    X = np.zeros((num, 4), dtype=np.float64, order="F")
+    rho = np.zeros((num, 4, 4), dtype=np.float64)
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    h = C.c_void_p()
+    _lib.check(ctx._lib.ray_forward_operator(ctx.handle, med.handle, _ptr(m), num, max(num, 1), float(dt),
+                                             _ptr(X), max(num, 1), _ptr(rho), _ptr(st), _ptr(nst),
+                                             C.byref(h)))
+    try:
+        n = C.c_int64()
+        _lib.check(ctx._lib.ray_frechet_count(h, C.byref(n)))
+        rows = np.zeros(n.value, dtype=np.int64)
+        cols = np.zeros(n.value, dtype=np.int64)
+        vals = np.zeros(n.value, dtype=np.float64)
+        _lib.check(ctx._lib.ray_frechet_export_coo(h, _ptr(rows), _ptr(cols), _ptr(vals), n.value,
+                                                   C.byref(n)))
+    finally:
+        ctx._lib.ray_frechet_destroy(h)
+    return rows, cols, vals, X, rho, {"status": st, "nsteps": nst}
+
+
+def ScatterForwardOperator(c, m, ext, dt, *, ctx=None, info=False, droptol=1e-12):
+    """NonObstacle.jl:189-243: returns (M, s).  s[:,1:4], s[:,9] are copied from m (:196) and
+    s[:,5:8] are the traced end states (:185); M is the (4 num) x N^2 Frechet matrix as a scipy
+    CSR matrix (rows ray-major like reshape(M, 4num, N^2) at :242, columns i + j*N), duplicates
+    summed by the sparse constructor and entries with |v| <= droptol dropped (droptol!, :242)."""
+    import scipy.sparse as sps
+    rows, cols, vals, X, rho, inf = forward_operator_coo(c, m, ext, dt, ctx=ctx)
+    num = X.shape[0]
+    N = (c.N if isinstance(c, GridMedium) else np.asarray(c).shape[0])
+    M = sps.coo_matrix((vals, (rows, cols)), shape=(4 * num, N * N)).tocsr()
+    if droptol is not None:
+        M.data[np.abs(M.data) <= droptol] = 0.0
+        M.eliminate_zeros()
+    s = np.zeros((num, 9), dtype=np.float64, order="F")
+    s[:, 0:4] = np.asarray(m)[:, 0:4]
+    s[:, 8] = np.asarray(m)[:, 8]
     s[:, 4:8] = X
-    return (None, s, inf) if info else (None, s)
+    inf["rho"] = rho
+    return (M, s, inf) if info else (M, s)
 
 
 def NonReflectionTrace(c, m, ext, dt, *, ctx=None, info=False):

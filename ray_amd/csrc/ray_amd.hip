@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared   (ray_amd/csrc/Makefile)
 #include "../../include/ray_amd.h"
 #include "ray_device.h"
+#include "ray_frechet.h"
 #include "ray_host_math.h"
 
 #include <cmath>
@@ -422,6 +423,8 @@ struct ray_medium {
     int N = 0;
     double ext = 0;
     double *d_c = nullptr, *d_rec = nullptr, *d_p = nullptr;
+    double *d_hrec = nullptr;                  // hess records, built on first use by the Frechet path
+    bool hess_valid = false;
     std::vector<double> p;                     // host copy of the nodes
 };
 
@@ -600,6 +603,21 @@ static int build_tables(ray_medium *med)
     hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
                        med->d_c, med->N, dx, med->d_rec);
     HIPCHK(hipGetLastError());
+    med->hess_valid = false;
+    return RAY_OK;
+}
+
+static int ensure_hess(ray_medium *med)
+{
+    if (med->hess_valid) return RAY_OK;
+    const int n1 = med->N - 1;
+    const int64_t cells = (int64_t)n1 * n1;
+    if (!med->d_hrec) HIPCHK(hipMalloc((void **)&med->d_hrec, (size_t)cells * 12 * sizeof(double)));
+    const double dx = 2 * med->ext / (med->N - 1);                      // NonObstacle.jl:191
+    hipLaunchKernelGGL(k_build_hess, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, med->ctx->stream,
+                       med->d_rec, med->N, dx, med->d_hrec);
+    HIPCHK(hipGetLastError());
+    med->hess_valid = true;
     return RAY_OK;
 }
 
@@ -695,6 +713,7 @@ int ray_medium_destroy(ray_medium *med)
     if (med->d_c) (void)hipFree(med->d_c);
     if (med->d_rec) (void)hipFree(med->d_rec);
     if (med->d_p) (void)hipFree(med->d_p);
+    if (med->d_hrec) (void)hipFree(med->d_hrec);
     delete med;
     return RAY_OK;
 }
@@ -704,7 +723,7 @@ static MediumDev medium_dev(const ray_medium *m)
     MediumDev d{};
     d.sp = m->sp;
     if (m->kind == kGrid) {
-        d.g.rec = m->d_rec; d.g.p = m->d_p; d.g.N = m->N;
+        d.g.rec = m->d_rec; d.g.hrec = m->d_hrec; d.g.p = m->d_p; d.g.N = m->N;
         d.g.p1 = m->p[0];
         d.g.h = m->p[1] - m->p[0];                                      // NonObstacle.jl:32
         d.g.rh = 1.0 / d.g.h;
@@ -965,6 +984,197 @@ int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_ho
     if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- complete forward operator: X, rho, Frechet contributions (NEXT-1) ------------------------------
+struct ray_frechet {
+    ray_ctx *ctx = nullptr;
+    int64_t num = 0;
+    int N = 0;
+    std::vector<int64_t> wave_base;     // slot-row offset per wave
+    std::vector<int32_t> steps;         // steps taken per ray
+    int64_t rows_total = 0;             // slot rows (each 64 lanes wide)
+    int32_t *d_cols = nullptr;
+    double *d_vals = nullptr;
+    std::vector<int32_t> h_cols;        // downloaded lazily by count / export
+    std::vector<double> h_vals;
+    bool on_host = false;
+};
+
+int ray_frechet_destroy(ray_frechet *f)
+{
+    if (!f) return RAY_OK;
+    if (f->ctx) (void)hipSetDevice(f->ctx->device);
+    if (f->d_cols) (void)hipFree(f->d_cols);
+    if (f->d_vals) (void)hipFree(f->d_vals);
+    delete f;
+    return RAY_OK;
+}
+
+int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld, double dt,
+                         double *X_host, int64_t ldx, double *rho_host, int32_t *status, int32_t *nsteps,
+                         ray_frechet **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med))) return rc;
+    if (med->kind != kGrid) return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator takes a gridded medium (NonObstacle.jl:189)");
+    if (med->N < 6) return fail(RAY_ERR_INVALID, "the Frechet path needs N >= 6 (hess table, NonObstacle.jl:212)");
+    if (!m_host || !X_host || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
+    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    const int max_steps = 1000000;
+    ray_frechet *f = new ray_frechet;
+    f->ctx = ctx; f->num = num; f->N = med->N;
+    f->steps.assign((size_t)num, 0);
+    if (num == 0) { *out = f; return RAY_OK; }
+    // slab sizing on the host: a ray takes at most floor(T/dt) + 2 steps (NonObstacle.jl:152-157)
+    const int64_t nwave = (num + 63) / 64;
+    std::vector<int32_t> cap((size_t)nwave, 0);
+    f->wave_base.assign((size_t)nwave, 0);
+    int64_t rows = 0;
+    for (int64_t w = 0; w < nwave; ++w) {
+        double tmax = 0;
+        for (int64_t r = w * 64; r < num && r < (w + 1) * 64; ++r) {
+            const double T = m_host[r + 8 * ld];
+            if (T > tmax) tmax = T;
+        }
+        double n = std::floor(tmax / dt) + 2;
+        if (!(tmax > 0)) n = 0;
+        if (n > max_steps) n = max_steps;
+        cap[(size_t)w] = (int32_t)n;
+        f->wave_base[(size_t)w] = rows;
+        rows += (int64_t)n * 24;
+    }
+    f->rows_total = rows;
+    const size_t slots = (size_t)rows * 64;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (slots * 36 + (size_t)num * 256 > free_b) {
+        ray_frechet_destroy(f);
+        return fail(RAY_ERR_NOMEM, "Frechet contribution slab does not fit in device memory (sum of T/dt too large)");
+    }
+    DevBuf dm, dX, drho, dbase, dcap;
+    RayOutBufs ob_;
+    hipError_t e = hipMalloc((void **)&f->d_cols, (slots ? slots : 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_vals, (slots ? slots : 1) * 4 * sizeof(double));
+    if (e == hipSuccess) e = dm.alloc(sizeof(double) * 9 * (size_t)num);
+    if (e == hipSuccess) e = dX.alloc(sizeof(double) * 4 * (size_t)num);
+    if (e == hipSuccess) e = drho.alloc(sizeof(double) * 16 * (size_t)num);
+    if (e == hipSuccess) e = dbase.alloc(sizeof(int64_t) * (size_t)nwave);
+    if (e == hipSuccess) e = dcap.alloc(sizeof(int32_t) * (size_t)nwave);
+    if (e != hipSuccess) {
+        std::string msg = std::string("ray_forward_operator: ") + hipGetErrorString(e);
+        ray_frechet_destroy(f);
+        return fail(e == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, msg);
+    }
+    if ((rc = ob_.alloc(num)) || (rc = ensure_hess(med))) { ray_frechet_destroy(f); return rc; }
+    bool okc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4) == RAY_OK &&
+               copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1) == RAY_OK;
+    if (okc) okc = hipMemcpyAsync(dbase.p, f->wave_base.data(), sizeof(int64_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (okc) okc = hipMemcpyAsync(dcap.p, cap.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (okc) okc = hipStreamSynchronize(ctx->stream) == hipSuccess;      // cap / wave_base are read by the copies above
+    if (!okc) { ray_frechet_destroy(f); return fail(RAY_ERR_HIP, "ray_forward_operator: upload failed"); }
+    FrechetArgs a{};
+    a.med = medium_dev(med);
+    a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
+    a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
+    a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>();
+    a.cols = f->d_cols; a.vals = f->d_vals;
+    a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
+    a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
+    a.step_counter = ctx->d_steps;
+    const dim3 grid((unsigned)nwave), block(64);
+    const size_t lds = (((size_t)med->N * 8 + 15) & ~(size_t)15);
+    hipEvent_t e0, e1;
+    time_begin(ctx, e0, e1);
+    if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, grid, block, lds, ctx->stream, a);
+    else hipLaunchKernelGGL(k_frechet<kExact>, grid, block, lds, ctx->stream, a);
+    time_end(ctx, e0, e1);
+    e = hipGetLastError();
+    if (e == hipSuccess) {
+        ctx->rays += (uint64_t)num;
+        ctx->launches += 1;
+        rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4);
+        if (!rc && rho_host) e = hipMemcpyAsync(rho_host, drho.p, sizeof(double) * 16 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream);
+        if (!rc && e == hipSuccess) e = hipMemcpyAsync(f->steps.data(), ob_.ns.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream);
+        if (!rc && e == hipSuccess) rc = ob_.fetch(ctx, num, status, nsteps, nullptr);
+    }
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+    if (rc || e != hipSuccess) {
+        std::string msg = rc ? g_err : std::string("ray_forward_operator: ") + hipGetErrorString(e);
+        ray_frechet_destroy(f);
+        return fail(rc ? rc : RAY_ERR_HIP, msg);
+    }
+    *out = f;
+    return RAY_OK;
+}
+
+static int frechet_download(ray_frechet *f)
+{
+    if (f->on_host) return RAY_OK;
+    int rc = use(f->ctx);
+    if (rc) return rc;
+    const size_t slots = (size_t)f->rows_total * 64;
+    f->h_cols.resize(slots);
+    f->h_vals.resize(slots * 4);
+    if (slots) {
+        HIPCHK(hipMemcpy(f->h_cols.data(), f->d_cols, slots * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(f->h_vals.data(), f->d_vals, slots * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    f->on_host = true;
+    return RAY_OK;
+}
+
+} // extern "C"
+// visits every non-zero contribution (row = 4*ray + r, col = node) in ray order
+template <class F>
+static void frechet_visit(const ray_frechet *f, F &&fn)
+{
+    for (int64_t i = 0; i < f->num; ++i) {
+        const int64_t base = f->wave_base[(size_t)(i >> 6)];
+        const int lane = (int)(i & 63);
+        const int64_t ne = (int64_t)f->steps[(size_t)i] * 24;
+        for (int64_t e = 0; e < ne; ++e) {
+            const size_t s = (size_t)((base + e) * 64 + lane);
+            const int32_t col = f->h_cols[s];
+            if (col < 0) continue;
+            for (int r = 0; r < 4; ++r) {
+                const double v = f->h_vals[s * 4 + r];
+                if (v != 0.0) fn(4 * i + r, (int64_t)col, v);
+            }
+        }
+    }
+}
+
+extern "C" {
+int ray_frechet_count(ray_frechet *f, int64_t *n)
+{
+    if (!f || !n) return fail(RAY_ERR_INVALID, "null argument");
+    int rc = frechet_download(f);
+    if (rc) return rc;
+    int64_t c = 0;
+    frechet_visit(f, [&](int64_t, int64_t, double) { ++c; });
+    *n = c;
+    return RAY_OK;
+}
+
+int ray_frechet_export_coo(ray_frechet *f, int64_t *rows, int64_t *cols, double *vals, int64_t cap, int64_t *n)
+{
+    if (!f || !rows || !cols || !vals || !n) return fail(RAY_ERR_INVALID, "null argument");
+    int rc = frechet_download(f);
+    if (rc) return rc;
+    int64_t c = 0;
+    bool over = false;
+    frechet_visit(f, [&](int64_t r, int64_t col, double v) {
+        if (c < cap) { rows[c] = r; cols[c] = col; vals[c] = v; } else over = true;
+        ++c;
+    });
+    *n = c;
+    if (over) return fail(RAY_ERR_INVALID, "export buffer too small (see ray_frechet_count)");
     return RAY_OK;
 }
 

@@ -24,6 +24,7 @@ constexpr int kBisectCap = 200;
 // so one right-hand side touches one or two 128-byte lines instead of 12 planes.
 struct GridDev {
     const double *rec;   // (N-1)*(N-1)*12
+    const double *hrec;  // (N-1)*(N-1)*12 hess records (Frechet path only; may be null)
     const double *p;     // N nodes, linspace(-ext, ext, N)
     int N;
     double p1;           // p[1] = -ext
@@ -208,6 +209,37 @@ __device__ __forceinline__ int cell_of(double x, const GridDev &g, int &oob)
     return i;
 }
 
+// H = [c^2 p ; -grad c * c * tau] from one cell record and the in-cell offsets (NonObstacle.jl:37-42),
+// in the chosen arithmetic flavour; also returns c, dc/dx, dc/dy, tau for the Jacobian path.
+template <int AR>
+__device__ __forceinline__ void h_from_record(const double X[4], double dx, double dy, const double2 r[6],
+                                              double H[4], double &c, double &gcX, double &gcY, double &tau)
+{
+    if (AR == kFused) {
+        // t0 + t1 dx + t2 dy + t3 dx dy = fma(dx, fma(dy, t3, t1), fma(dy, t2, t0))
+        tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
+        c = __builtin_fma(dx, __builtin_fma(dy, r[1].y, r[0].y), __builtin_fma(dy, r[1].x, r[0].x));
+        gcX = __builtin_fma(dx, __builtin_fma(dy, r[3].y, r[2].y), __builtin_fma(dy, r[3].x, r[2].x));
+        gcY = __builtin_fma(dx, __builtin_fma(dy, r[5].y, r[4].y), __builtin_fma(dy, r[5].x, r[4].x));
+        const double c2 = c * c, w = c * tau;
+        H[0] = c2 * X[2];
+        H[1] = c2 * X[3];
+        H[2] = (-gcX) * w;
+        H[3] = (-gcY) * w;
+    } else {
+        const double dxdy = dx * dy;
+        tau = X[2] * X[2] + X[3] * X[3];
+        c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
+        gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
+        gcY = ((r[4].x + dx * r[4].y) + dy * r[5].x) + dxdy * r[5].y;
+        const double c2 = c * c;
+        H[0] = c2 * X[2];
+        H[1] = c2 * X[3];
+        H[2] = ((-gcX) * c) * tau;
+        H[3] = ((-gcY) * c) * tau;
+    }
+}
+
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
 // ALL 64 lanes must be converged here (wave-cooperative record fetch).
 template <int AR>
@@ -221,29 +253,8 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
     double2 r[6];
     fetch_records(g, a, cid, r);
     const double dx = X[0] - pi_, dy = X[1] - pj_;
-    if (AR == kFused) {
-        // t0 + t1 dx + t2 dy + t3 dx dy = fma(dx, fma(dy, t3, t1), fma(dy, t2, t0))
-        const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
-        const double c = __builtin_fma(dx, __builtin_fma(dy, r[1].y, r[0].y), __builtin_fma(dy, r[1].x, r[0].x));
-        const double gcX = __builtin_fma(dx, __builtin_fma(dy, r[3].y, r[2].y), __builtin_fma(dy, r[3].x, r[2].x));
-        const double gcY = __builtin_fma(dx, __builtin_fma(dy, r[5].y, r[4].y), __builtin_fma(dy, r[5].x, r[4].x));
-        const double c2 = c * c, w = c * tau;
-        H[0] = c2 * X[2];
-        H[1] = c2 * X[3];
-        H[2] = (-gcX) * w;
-        H[3] = (-gcY) * w;
-    } else {
-        const double dxdy = dx * dy;
-        const double tau = X[2] * X[2] + X[3] * X[3];
-        const double c = ((r[0].x + dx * r[0].y) + dy * r[1].x) + dxdy * r[1].y;
-        const double gcX = ((r[2].x + dx * r[2].y) + dy * r[3].x) + dxdy * r[3].y;
-        const double gcY = ((r[4].x + dx * r[4].y) + dy * r[5].x) + dxdy * r[5].y;
-        const double c2 = c * c;
-        H[0] = c2 * X[2];
-        H[1] = c2 * X[3];
-        H[2] = ((-gcX) * c) * tau;
-        H[3] = ((-gcY) * c) * tau;
-    }
+    double c, gcX, gcY, tau;
+    h_from_record<AR>(X, dx, dy, r, H, c, gcX, gcY, tau);
 }
 
 // z' * eval[I,J,:] alone (c at the sensor for the initial slowness)  NonObstacle.jl:39,62

@@ -1,0 +1,326 @@
+// ray_frechet.h -- NEXT-1 of SURVEY.md section 8f: the Jacobian rho and the Frechet matrix M of
+// ScatterForwardOperator (NonObstacle.jl:6-28 DiscreteHamilton with Hessian, :107-139 dV,
+// :141-187 ChunkProcessing!, :212-218 hess table).
+//
+// The reference builds, per ray and per RK4 step, three 4 x N^2 sparse matrices (O(N^2) each) and a
+// dense 4num x N^2 SharedArray.  Here one thread integrates (X, rho) for one ray and EMITS the
+// 12-node stencil contributions Theta = inv(rho) dV w of every quadrature point into a per-wave slab
+// [slot][lane] (coalesced); after the loop it multiplies its own slots by the final rho.  The host
+// (or the caller's sparse constructor, exactly like the reference's sparse() at :137,242) merges
+// duplicate columns.  The reference goes through LAPACK inv / BLAS gemm here, so parity is by
+// tolerance; the X trajectory itself is bit-identical to k_trace (same expressions).
+#pragma once
+#include "ray_device.h"
+
+namespace ray {
+
+constexpr int kFrSlotsPerCall = 12;     // nodes touched by one dV evaluation
+
+// hess records (NonObstacle.jl:212-218): [hess[I,J,1:4] | hess[I,J,5:8] | hess[I,J,9:12]] per cell,
+// same cell indexing as the eval/grad records; zero where the reference never writes.
+__global__ __launch_bounds__(256) void k_build_hess(const double *__restrict__ rec, int N, double dx,
+                                                    double *__restrict__ hrec)
+{
+    const int n1 = N - 1;
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n1 * n1) return;
+    const int i = (int)(id % n1), j = (int)(id / n1);            // cell (I,J) = (i+1, j+1)
+    double out[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) out[k] = 0.0;
+    if (i >= 2 && i <= N - 4 && j >= 2 && j <= N - 4) {          // I,J in 3..N-3
+        const double two_dx = 2 * dx;
+        const double *e = rec + (size_t)(id + 1) * 12, *w = rec + (size_t)(id - 1) * 12;
+        const double *n = rec + (size_t)(id + n1) * 12, *s = rec + (size_t)(id - n1) * 12;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out[k] = (e[4 + k] - w[4 + k]) / two_dx;             // grad[I+1,J,1:4] - grad[I-1,J,1:4]
+            out[4 + k] = (n[4 + k] - s[4 + k]) / two_dx;         // grad[I,J+1,1:4] - grad[I,J-1,1:4]
+            out[8 + k] = (n[8 + k] - s[8 + k]) / two_dx;         // grad[I,J+1,5:8] - grad[I,J-1,5:8]
+        }
+    }
+    double2 *r = reinterpret_cast<double2 *>(hrec) + (size_t)id * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = make_double2(out[2 * k], out[2 * k + 1]);
+}
+
+struct PointEval {
+    int i, j;                 // 0-based cell
+    double dx, dy, c, gcX, gcY, tau;
+};
+
+// table look-up at X (per-lane loads), H in the chosen flavour          NonObstacle.jl:30-42
+template <int AR>
+__device__ __forceinline__ void point_eval(const GridDev &g, const double X[4], double H[4], PointEval &q, int &oob)
+{
+    q.i = cell_of<AR>(X[0], g, oob);
+    q.j = cell_of<AR>(X[1], g, oob);
+    const unsigned cid = mad24((unsigned)q.j, (unsigned)(g.N - 1), (unsigned)q.i);
+    const double *pt = lds_nodes();
+    q.dx = X[0] - pt[q.i];
+    q.dy = X[1] - pt[q.j];
+    const double2 *src = reinterpret_cast<const double2 *>(g.rec) + (size_t)cid * 6;
+    double2 r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = src[k];
+    h_from_record<AR>(X, q.dx, q.dy, r, H, q.c, q.gcX, q.gcY, q.tau);
+}
+
+__device__ __forceinline__ double bil(double dx, double dy, double dxdy, double2 a, double2 b)
+{
+    return ((a.x + dx * a.y) + dy * b.x) + dxdy * b.y;           // z' * [a.x a.y b.x b.y]
+}
+
+// a3: H and Jm = dH/dX (row-major 4x4).                           NonObstacle.jl:6-28
+// M = [2*c*X[3:4]*g'  c^2*eye(2); -(c*h + g*g')*tau  -2*c*g*X[3:4]']
+template <int AR>
+__device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4], double H[4], double Jm[16], int &oob)
+{
+    PointEval q;
+    point_eval<AR>(g, X, H, q, oob);
+    // hess exists for I,J <= N-3 only: clamp + flag (reference: out-of-bounds read)
+    const int ih = q.i < g.N - 4 ? q.i : g.N - 4, jh = q.j < g.N - 4 ? q.j : g.N - 4;
+    oob |= (ih != q.i) | (jh != q.j);
+    const double2 *hs = reinterpret_cast<const double2 *>(g.hrec) + ((size_t)ih + (size_t)jh * (size_t)(g.N - 1)) * 6;
+    const double dxdy = q.dx * q.dy;
+    const double hXX = bil(q.dx, q.dy, dxdy, hs[0], hs[1]);
+    const double hXY = bil(q.dx, q.dy, dxdy, hs[2], hs[3]);
+    const double hYY = bil(q.dx, q.dy, dxdy, hs[4], hs[5]);
+    const double c = q.c, tau = q.tau, c2 = c * c;
+    const double gv[2] = {q.gcX, q.gcY};
+    const double hv[2][2] = {{hXX, hXY}, {hXY, hYY}};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            Jm[a * 4 + b] = ((2 * c) * X[2 + a]) * gv[b];
+            Jm[a * 4 + 2 + b] = (a == b) ? c2 : 0.0;
+            Jm[(2 + a) * 4 + b] = (-(c * hv[a][b] + gv[a] * gv[b])) * tau;
+            Jm[(2 + a) * 4 + 2 + b] = ((-2 * c) * gv[a]) * X[2 + b];
+        }
+}
+
+__device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = A[i * 4] * B[j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s = __builtin_fma(A[i * 4 + k], B[k * 4 + j], s);
+            C[i * 4 + j] = s;
+        }
+}
+
+// inverse of a well-conditioned 4x4 (rho is a perturbation of a symplectic matrix, det ~ 1) by the
+// adjugate through 2x2 sub-determinants; the reference calls LAPACK inv (NonObstacle.jl:158).
+__device__ __forceinline__ void mat4_inv(const double m[16], double inv[16])
+{
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double id = 1.0 / det;
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+}
+
+struct FrechetArgs {
+    MediumDev med;
+    const double *m;            // (num, 9): initial states and T
+    int64_t num, ld;
+    double dt;
+    int max_steps;
+    double cease_r;
+    const int64_t *wave_base;   // slot offset of every wave (in units of 64-lane slot rows)
+    const int32_t *wave_cap;    // step capacity of every wave
+    int32_t *cols;              // [slot row][lane] node index (0-based, first index x) or -1
+    double *vals;               // [slot row][lane][4]
+    double *X;                  // (num, 4) end states
+    int64_t ldx;
+    double *rho;                // (num, 16) final Jacobian, row-major; may be null
+    int32_t *status, *nsteps;
+    unsigned long long *step_counter;
+};
+
+// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> slots [e, e+12) of this lane.
+// dV: NonObstacle.jl:107-139.
+template <int AR>
+__device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const double rho[16], double w,
+                                           bool live, int64_t row0, unsigned lane, int &oob)
+{
+    double H[4];
+    PointEval q;
+    int o = 0;
+    point_eval<AR>(a.med.g, X, H, q, o);
+    double inv[16];
+    mat4_inv(rho, inv);
+    const GridDev &g = a.med.g;
+    const double h = g.h;
+    const double u = q.dx / h, v = q.dy / h;
+    const double phi[4] = {(1 - u) * (1 - v), u * (1 - v), (1 - u) * v, u * v};
+    const double psi[4] = {u * (1 - v), -(1 - u) * (1 - v), u * v, -(1 - u) * v};
+    const double gam[4] = {(1 - u) * v, u * v, -(1 - u) * (1 - v), -u * (1 - v)};
+    const double ct2h = q.c * q.tau / (2 * h);
+    const int N = g.N;
+    // node offsets relative to (i, j): cell nodes, x-neighbours (row 3), y-neighbours (row 4)
+    const int di[12] = {0, 1, 0, 1, 2, -1, 2, -1, 0, 1, 0, 1};
+    const int dj[12] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, -1, -1};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int ni = q.i + di[k], nj = q.j + dj[k];
+        const bool ok = ni >= 0 && ni < N && nj >= 0 && nj < N;
+        o |= !ok;
+        double th[4];
+        if (k < 4) {
+            const double A0 = 2 * q.c * X[2] * phi[k], A1 = 2 * q.c * X[3] * phi[k];
+            const double A2 = -q.tau * q.gcX * phi[k] + ct2h * psi[k];
+            const double A3 = -q.tau * q.gcY * phi[k] + ct2h * gam[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                th[r] = (((inv[r * 4] * A0 + inv[r * 4 + 1] * A1) + inv[r * 4 + 2] * A2) + inv[r * 4 + 3] * A3) * w;
+        } else if (k < 8) {
+            const double A2 = -ct2h * psi[k - 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 2] * A2) * w;
+        } else {
+            const double A3 = -ct2h * gam[k - 8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 3] * A3) * w;
+        }
+        const int64_t s = (row0 + k) * 64 + lane;
+        a.cols[s] = (live && ok) ? ni + nj * N : -1;
+        double2 *dst = reinterpret_cast<double2 *>(a.vals + s * 4);
+        dst[0] = make_double2(th[0], th[1]);
+        dst[1] = make_double2(th[2], th[3]);
+    }
+    if (live) oob |= o;
+}
+
+// ChunkProcessing! for one ray per thread                         NonObstacle.jl:146-185
+template <int AR>
+__global__ __launch_bounds__(256) void k_frechet(const FrechetArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = r < a.num;
+    const unsigned lane = threadIdx.x & 63;
+    const int64_t wave = r >> 6;
+    // node table into LDS (the look-ups read it from there)
+    {
+        double *p_lds = reinterpret_cast<double *>(ray_smem);
+        for (int k = threadIdx.x; k < a.med.g.N; k += blockDim.x) p_lds[k] = a.med.g.p[k];
+        __syncthreads();
+    }
+    const int64_t base = a.wave_base[wave];
+    const int cap = a.wave_cap[wave];
+    double X[4] = {0, 0, 1, 0}, T = 0;
+    double rho[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int steps = 0, st = 0, oob = 0, it = 0;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = a.m[r + k * a.ld];
+        T = a.m[r + 8 * a.ld];
+        if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;
+    }
+    double t = 0, dt = a.dt;
+    bool active = valid && t < T;
+    while (__any(active)) {
+        if (it >= cap || it >= a.max_steps) break;
+        double dtl = 0.0;
+        if (active) {
+            if ((t + dt) > T) dt = T - t;                                    // :153-156
+            t = t + dt;                                                      // :157
+            dtl = dt;
+        }
+        emit_theta<AR>(a, X, rho, dtl * 0.5, active, base + (int64_t)it * 24, lane, oob);           // :158-159
+        // RK4 for X (bit-identical to k_trace) and rho                       :161-172
+        double k1[4], H[4], Y[4], accx[4], Jm[16], V[16], R[16], accr[16];
+        int o = 0;
+        const double hdt = 0.5 * dtl;
+        hamilton_jac<AR>(a.med.g, X, k1, Jm, o);
+        mat4_mul(Jm, rho, V);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { accx[k] = k1[k]; Y[k] = (AR == kFused) ? __builtin_fma(k1[k], hdt, X[k]) : X[k] + k1[k] * hdt; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { accr[k] = V[k]; R[k] = __builtin_fma(V[k], hdt, rho[k]); }
+        hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
+        mat4_mul(Jm, R, V);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], hdt, X[k]) : X[k] + H[k] * hdt; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { accr[k] = __builtin_fma(2.0, V[k], accr[k]); R[k] = __builtin_fma(V[k], hdt, rho[k]); }
+        hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
+        mat4_mul(Jm, R, V);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], dtl, X[k]) : X[k] + H[k] * dtl; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { accr[k] = __builtin_fma(2.0, V[k], accr[k]); R[k] = __builtin_fma(V[k], dtl, rho[k]); }
+        hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
+        mat4_mul(Jm, R, V);
+        const double dt6 = dtl * 0.16666666666666666;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            X[k] = (AR == kFused) ? __builtin_fma(accx[k] + H[k], dt6, X[k]) : X[k] + div6((accx[k] + H[k]) * dtl);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) rho[k] = __builtin_fma(accr[k] + V[k], dt6, rho[k]);
+        ++it;
+        double w2 = dtl * 0.5;                                               // :174-175
+        if (active) {
+            steps = it;
+            const double s = X[0] * X[0] + X[1] * X[1];
+            oob |= o | !(s == s);
+            const double c2 = a.cease_r * a.cease_r;
+            bool out;
+            if (s > c2 * 1.0000000001) out = true;
+            else if (s < c2 * 0.9999999999) out = false;
+            else out = __builtin_sqrt(s) > a.cease_r;
+            if (out) { w2 = w2 + (T - t); t = t + (T - t); st |= kStCeased; }   // :177-181 (same X, rho: one emission)
+        }
+        emit_theta<AR>(a, X, rho, w2, active, base + (int64_t)it * 24 - 12, lane, oob);
+        if (active) active = t < T;
+    }
+    if (active) st |= kStStepCap;
+    if (oob) st |= kStOob;
+    // M rows = rho * Phi (:184): apply the final rho to this ray's own contributions
+    if (valid) {
+        for (int e = 0; e < steps * 24; ++e) {
+            const int64_t s = (base + e) * 64 + lane;
+            double2 *p2 = reinterpret_cast<double2 *>(a.vals + s * 4);
+            const double2 lo = p2[0], hi = p2[1];
+            double o4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                o4[i] = ((rho[i * 4] * lo.x + rho[i * 4 + 1] * lo.y) + rho[i * 4 + 2] * hi.x) + rho[i * 4 + 3] * hi.y;
+            p2[0] = make_double2(o4[0], o4[1]);
+            p2[1] = make_double2(o4[2], o4[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.X[r + k * a.ldx] = X[k];
+        if (a.rho) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a.rho[r * 16 + k] = rho[k];
+        }
+        if (a.status) a.status[r] = st;
+        if (a.nsteps) a.nsteps[r] = steps;
+    }
+    const unsigned wsum = wave_sum((unsigned)steps);
+    if (lane == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+}
+
+} // namespace ray

@@ -1,0 +1,97 @@
+"""GPU parity of the complete ScatterForwardOperator (SURVEY.md section 8f NEXT-1; NonObstacle.jl:189-243)
+through the C ABI: end states bit-exact against the fixed-time trace, Jacobian rho and Frechet
+matrix M against the oracle's restatement by tolerance (the reference itself goes through LAPACK
+inv / BLAS gemm for these, so no bit pattern is defined; 1e-10 relative to the largest entry)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MTOL = 1e-10
+
+
+@pytest.fixture(params=[0, 1], ids=["exact", "fused"])
+def arith(ctx, request):
+    import ray_amd
+    ctx.set_arith(request.param)
+    yield request.param
+    ctx.set_arith(ray_amd.ARITH_FUSED)
+
+
+def _data(orc, N, ns, nd, arith, bump=0.0):
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    m, *_ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2)
+    if bump:
+        m[:, 8] *= 1.0 + bump * np.arange(m.shape[0]) / m.shape[0]
+    return c, tab, np.asfortranarray(m)
+
+
+@pytest.mark.parametrize("N,ns,nd,dt", [(31, 4, 16, 5e-2), (61, 5, 13, 5e-2), (75, 3, 70, 2e-2)])
+def test_forward_operator_matches_oracle(ctx, orc, arith, N, ns, nd, dt):
+    import ray_amd
+    c, tab, m = _data(orc, N, ns, nd, arith)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    M, s, info = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(info["nsteps"], nso)
+    assert np.array_equal(info["status"], sto)
+    assert np.array_equal(s[:, 4:8], Xo)                       # same expressions as the trace kernel
+    Xt, _ = ray_amd._trace(med, m, 1.5, dt, ray_amd.TRACE_SHORTEN_CEASE, ctx, True)
+    assert np.array_equal(s[:, 4:8], Xt)
+    assert np.max(np.abs(info["rho"] - rho_o)) <= MTOL * np.max(np.abs(rho_o))
+    Md = M.toarray()
+    assert Md.shape == Mo.shape
+    assert np.max(np.abs(Md - Mo)) <= MTOL * np.max(np.abs(Mo))
+    # symplectic flow: det(rho) = 1 up to the integrator's O(dt^4) defect
+    assert np.max(np.abs(np.linalg.det(info["rho"]) - 1.0)) < 1e-3
+
+
+def test_forward_operator_droptol_and_shape(ctx, orc):
+    import ray_amd
+    c, tab, m = _data(orc, 41, 4, 9, 1)
+    M, s = ray_amd.ScatterForwardOperator(c, m, 1.5, 5e-2, ctx=ctx)
+    assert M.shape == (4 * m.shape[0], 41 * 41)
+    assert M.nnz > 0 and np.all(np.abs(M.data) > 1e-12)
+    assert np.array_equal(s[:, 0:4], m[:, 0:4]) and np.array_equal(s[:, 8], m[:, 8])
+
+
+def test_forward_operator_cease_and_zero_time(ctx, orc, arith):
+    """travel times stretched by up to 60%: late rays leave the 1+2h disc and take the cease branch
+    (NonObstacle.jl:177-181); rows with T = 0 contribute nothing and keep rho = I."""
+    import ray_amd
+    c, tab, m = _data(orc, 51, 4, 20, arith, bump=0.6)
+    m[::7, 8] = 0.0
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, 5e-2)
+    assert (sto & 16).any()
+    M, s, info = ray_amd.ScatterForwardOperator(c, m, 1.5, 5e-2, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(info["status"], sto) and np.array_equal(info["nsteps"], nso)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+    assert np.array_equal(info["rho"][::7], np.broadcast_to(np.eye(4), info["rho"][::7].shape))
+    assert M[0:4].nnz == 0
+
+
+def test_forward_operator_empty_and_errors(ctx, orc):
+    import ray_amd
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 31, 1.5)
+    M, s = ray_amd.ScatterForwardOperator(c, np.zeros((0, 9), order="F"), 1.5, 5e-2, ctx=ctx)
+    assert M.shape == (0, 31 * 31) and s.shape == (0, 9)
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.ScatterForwardOperator(ray_amd.SinProd.smooth_demo(), np.zeros((1, 9), order="F"), 1.5, 5e-2, ctx=ctx)
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.ScatterForwardOperator(c, np.ones((2, 9), order="F"), 1.5, 0.0, ctx=ctx)
+
+
+def test_forward_operator_after_update(ctx, orc):
+    """the hess records follow ray_medium_update_grid (one medium object across iterates,
+    NonObstacle.jl:333 inside the reconstruction loop)."""
+    import ray_amd
+    c, tab, m = _data(orc, 41, 3, 11, 1)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ray_amd.ScatterForwardOperator(med, m, 1.5, 5e-2, ctx=ctx)
+    c2 = np.asfortranarray(1.0 + 0.5 * (c - 1.0))
+    med.update(c2)
+    M, s = ray_amd.ScatterForwardOperator(med, m, 1.5, 5e-2, ctx=ctx, droptol=None)
+    Xo, _, Mo, _, _ = orc.forward_operator(orc.GridTables(c2, 1.5, 1), m, 5e-2)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
