@@ -156,20 +156,24 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
  * Jacobian rho (NonObstacle.jl:149,166-172; rho_host: num x 16 row-major, may be NULL) and its
  * 4 x N^2 block rho*Phi of the Frechet matrix M (NonObstacle.jl:158-159,174-184; dV :107-139,
  * DiscreteHamilton with Hessian :6-28, hess table :212-218).
- * The reference assembles M densely (4num x N^2 SharedArray) and calls sparse()/droptol! (:242).
- * Here the un-merged stencil contributions are returned as COO triplets, ray by ray:
- *   rows[k] = 4*ray + component (0-based), cols[k] = i + j*N (0-based node, first index x),
- * duplicates NOT summed: feed them to the caller's sparse constructor (Julia sparse(I,J,V,m,n),
- * scipy coo_matrix(...).tocsr()), which sums duplicates exactly like the reference's sparse() at
- * :137, then apply droptol (1e-12, :242).  Parity is by tolerance (the reference goes through
- * LAPACK inv / BLAS gemm).                                                                      */
+ * The reference assembles M densely (4num x N^2 SharedArray) and compresses it with
+ * sparse()/droptol! (:242).  Here M is assembled sparse on the device and handed over as CSR:
+ *   row 4*ray + component (0-based; = reshape(M, 4num, N^2) at :242), column i + j*N (0-based node,
+ *   first index x), columns sorted within a row, duplicates summed in emission order, entries with
+ *   |v| <= droptol removed (the reference passes 1e-12; droptol < 0 keeps every stencil entry).
+ * A Julia caller gets the reference's SparseMatrixCSC with
+ *   copy(transpose(SparseMatrixCSC(N^2, 4num, indptr .+ 1, indices .+ 1, data)))  (julia/RayAMD.jl).
+ * Limits: 4*num < 2^31; at most 1364 steps per ray (T/dt).  Parity is by tolerance: the reference
+ * goes through LAPACK inv / BLAS gemm for rho and Phi.                                           */
 typedef struct ray_frechet ray_frechet;
 int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld,
-                         double dt, double *X_host, int64_t ldx, double *rho_host, int32_t *status,
-                         int32_t *nsteps, ray_frechet **out);
-int ray_frechet_count(ray_frechet *f, int64_t *n_triplets);
-int ray_frechet_export_coo(ray_frechet *f, int64_t *rows, int64_t *cols, double *vals, int64_t cap,
-                           int64_t *n_written);
+                         double dt, double droptol, double *X_host, int64_t ldx, double *rho_host,
+                         int32_t *status, int32_t *nsteps, ray_frechet **out);
+int ray_frechet_shape(ray_frechet *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* indptr: 4num + 1, indices / data: nnz (host buffers) */
+int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, double *data);
+/* the same three arrays where they live in HBM (valid until ray_frechet_destroy) */
+int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data);
 int ray_frechet_destroy(ray_frechet *f);
 
 /* ---- misfit (NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252) ------------------

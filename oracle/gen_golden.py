@@ -79,6 +79,20 @@ def main():
     sm, st, mask = P.misfit(m58, o58, 0.2)
     np.savez(os.path.join(OUT, "misfit_grid_n75.npz"), sum_mismatch2=sm, sum_target2=st,
              mask=np.array(mask, dtype=np.uint8))
+    # NEXT-1: complete ScatterForwardOperator on an N=31 grid: X, rho, M (non-zeros of the dense result)
+    N3, ns3, nd3 = 31, 4, 8
+    p3 = P.linspace(-ext, ext, N3)
+    c3 = [sp.c(p3[i], p3[j]) for j in range(N3) for i in range(N3)]
+    g3 = P.Grid(c3, N3, ext)
+    rows3 = P.init_states(g3, ns3, nd3, 0.0, pi)
+    shot3 = P.shoot(g3, rows3, dt)
+    T3 = [o[1] * (1.0 + 0.4 * k / len(shot3)) for k, o in enumerate(shot3)]      # late rays take the cease branch
+    M3, X3, rho3 = P.forward_operator(g3, rows3, T3, 5e-2)
+    r_, c_ = np.nonzero(M3)
+    np.savez(os.path.join(OUT, "frechet_n31_ns4_nd8.npz"), N=N3, ext=ext, trace_dt=5e-2,
+             c=np.array(c3).reshape(N3, N3, order="F"), rows=np.array([list(r) for r in rows3]), T=np.array(T3),
+             X=np.array(X3), rho=np.array(rho3), M_rows=r_.astype(np.int32), M_cols=c_.astype(np.int32),
+             M_vals=M3[r_, c_])
     print("golden fixtures written to", os.path.normpath(OUT))
 
 

@@ -281,3 +281,112 @@ def misfit(m58, obs58, thresh):
         na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3])
         mask.append(1 if nd_ / na < thresh else 0)
     return sm, st, mask
+
+
+# ---- NEXT-1: Jacobian rho and Frechet matrix M (NonObstacle.jl:6-28,107-139,146-185,212-218) ----------
+# Written against the reference text independently of ray_oracle.c, with numpy's LAPACK-backed
+# inv / matmul for the 4x4 algebra (what the reference's `inv(rho) * ...` and `t1 * rho` call).
+# The C oracle uses its own elimination and loop order, so the two agree to rounding (~1e-13
+# relative), not bit for bit; tests/test_oracle.py compares them at 1e-10.
+def _hess_table(grid):
+    """hess[I,J] (12 numbers) for I,J in 1..N-3; rows 1,2 stay zero (NonObstacle.jl:194,212-218)."""
+    N, gr = grid.N, grid.gr
+    dx = 2 * grid.ext / (N - 1)
+    he = {(I, J): [0.0] * 12 for I in range(1, N - 2) for J in range(1, N - 2)}
+    for I in range(3, N - 2):
+        for J in range(3, N - 2):
+            he[I, J] = [(gr[I + 1, J][k] - gr[I - 1, J][k]) / (2 * dx) for k in range(4)] + \
+                       [(gr[I, J + 1][k] - gr[I, J - 1][k]) / (2 * dx) for k in range(4)] + \
+                       [(gr[I, J + 1][4 + k] - gr[I, J - 1][4 + k]) / (2 * dx) for k in range(4)]
+    return he
+
+
+def _point(grid, X):
+    import numpy as np
+    I, _ = grid._cell(X[0])
+    J, _ = grid._cell(X[1])
+    h = grid.p[1] - grid.p[0]
+    dx, dy = X[0] - grid.p[I - 1], X[1] - grid.p[J - 1]
+    z = np.array([1.0, dx, dy, dx * dy])
+    tau = X[2] * X[2] + X[3] * X[3]
+    c = float(z @ np.array(grid.ev[I, J]))
+    g = grid.gr[I, J]
+    return I, J, h, dx, dy, z, tau, c, float(z @ np.array(g[0:4])), float(z @ np.array(g[4:8]))
+
+
+def hamilton_jacobian(grid, he, X):
+    """NonObstacle.jl:20-25: the 4x4 matrix the reference calls M (here Jm)."""
+    import numpy as np
+    I, J, h, dx, dy, z, tau, c, gcX, gcY = _point(grid, X)
+    Ih, Jh = min(I, grid.N - 3), min(J, grid.N - 3)
+    hs = he[Ih, Jh]
+    hXX, hXY, hYY = float(z @ np.array(hs[0:4])), float(z @ np.array(hs[4:8])), float(z @ np.array(hs[8:12]))
+    hh = np.array([[hXX, hXY], [hXY, hYY]])
+    g = np.array([gcX, gcY])
+    P = np.array([X[2], X[3]])
+    return np.block([[2 * c * np.outer(P, g), c * c * np.eye(2)],
+                     [-(c * hh + np.outer(g, g)) * tau, -2 * c * np.outer(g, P)]])
+
+
+def dV(grid, X):
+    """NonObstacle.jl:107-139 as a dense 4 x N^2 array (duplicates summed like sparse(), :137)."""
+    import numpy as np
+    N = grid.N
+    I, J, h, dx, dy, z, tau, c, gcX, gcY = _point(grid, X)
+    u, v = dx / h, dy / h
+    phi = np.array([(1 - u) * (1 - v), u * (1 - v), (1 - u) * v, u * v])
+    psi = np.array([u * (1 - v), -(1 - u) * (1 - v), u * v, -(1 - u) * v])
+    gam = np.array([(1 - u) * v, u * v, -(1 - u) * (1 - v), -u * (1 - v)])
+    cell = [I + (J - 1) * N, I + 1 + (J - 1) * N, I + J * N, I + 1 + J * N]
+    Rind = [1] * 4 + [2] * 4 + [3] * 8 + [4] * 8
+    Cind = cell + cell + cell + [I + 2 + (J - 1) * N, I - 1 + (J - 1) * N, I + 2 + J * N, I - 1 + J * N] + \
+        cell + [I + (J + 1) * N, I + 1 + (J + 1) * N, I + (J - 2) * N, I + 1 + (J - 2) * N]
+    Vind = np.concatenate([2 * c * X[2] * phi, 2 * c * X[3] * phi,
+                           -tau * gcX * phi + c * tau * psi / (2 * h), -c * tau * psi / (2 * h),
+                           -tau * gcY * phi + c * tau * gam / (2 * h), -c * tau * gam / (2 * h)])
+    A = np.zeros((4, N * N))
+    for r, cc, vv in zip(Rind, Cind, Vind):
+        A[r - 1, cc - 1] += vv
+    return A
+
+
+def forward_operator(grid, rows, T, timeStep):
+    """ChunkProcessing! (NonObstacle.jl:146-185) for every ray: returns (M (4num, N^2) dense,
+    X list, rho list).  X follows the same expressions as trace_fixed_time(mode 0)."""
+    import numpy as np
+    he = _hess_table(grid)
+    N = grid.N
+    cease_r = 1 + 2 * (grid.p[1] - grid.p[0])
+    M = np.zeros((4 * len(rows), N * N))
+    Xs, rhos = [], []
+    for i, (X0, Ti) in enumerate(zip(rows, T)):
+        X = list(X0)
+        t, dt = 0, timeStep
+        rho = np.eye(4)
+        Phi = np.zeros((4, N * N))
+        while t < Ti:
+            if (t + dt) > Ti:
+                dt = Ti - t
+            t = t + dt
+            Phi += np.linalg.inv(rho) @ dV(grid, X) * dt / 2
+            k1, _ = grid.hamilton(X); t1 = hamilton_jacobian(grid, he, X)
+            Y = [X[k] + k1[k] / 2 * dt for k in range(4)]
+            k2, _ = grid.hamilton(Y); t2 = hamilton_jacobian(grid, he, Y)
+            Y = [X[k] + k2[k] / 2 * dt for k in range(4)]
+            k3, _ = grid.hamilton(Y); t3 = hamilton_jacobian(grid, he, Y)
+            Y = [X[k] + k3[k] * dt for k in range(4)]
+            k4, _ = grid.hamilton(Y); t4 = hamilton_jacobian(grid, he, Y)
+            v1 = t1 @ rho
+            v2 = t2 @ (rho + v1 * dt / 2)
+            v3 = t3 @ (rho + v2 * dt / 2)
+            v4 = t4 @ (rho + v3 * dt)
+            X = [X[k] + (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) * dt / 6.0 for k in range(4)]
+            rho = rho + (v1 + 2 * v2 + 2 * v3 + v4) * dt / 6.0
+            Phi += np.linalg.inv(rho) @ dV(grid, X) * dt / 2
+            if sqrt(X[0] * X[0] + X[1] * X[1]) > cease_r:
+                Phi += np.linalg.inv(rho) @ dV(grid, X) * (Ti - t)
+                t = t + (Ti - t)
+        M[4 * i:4 * i + 4, :] = rho @ Phi
+        Xs.append(X)
+        rhos.append(rho)
+    return M, Xs, rhos

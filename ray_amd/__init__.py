@@ -271,11 +271,45 @@ def _trace(c, m, ext, dt, mode, ctx, info):
     return X, {"status": st, "nsteps": nst}
 
 
-def forward_operator_coo(c, m, ext, dt, *, ctx=None):
+class FrechetMatrix:
+    """Device-resident CSR form of the Frechet matrix M (ray_frechet handle): rows 4*ray + component,
+    columns i + j*N.  `.tocsr()` copies it to a scipy.sparse.csr_matrix."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+        r, c, n = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(ctx._lib.ray_frechet_shape(handle, C.byref(r), C.byref(c), C.byref(n)))
+        self.shape, self.nnz = (r.value, c.value), n.value
+
+    def tocsr(self):
+        import scipy.sparse as sps
+        indptr = np.zeros(self.shape[0] + 1, dtype=np.int64)
+        indices = np.zeros(self.nnz, dtype=np.int32)
+        data = np.zeros(self.nnz, dtype=np.float64)
+        _lib.check(self.ctx._lib.ray_frechet_export_csr(self.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
+        return sps.csr_matrix((data, indices, indptr), shape=self.shape)
+
+    def device_arrays(self):
+        """(indptr, indices, data) device addresses (int64[4num+1], int32[nnz], float64[nnz])."""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self.ctx._lib.ray_frechet_csr_dev(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def close(self):
+        if self.handle:
+            self.ctx._lib.ray_frechet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def forward_operator_dev(c, m, ext, dt, *, ctx=None, droptol=1e-12):
     """The complete ChunkProcessing! pass (NonObstacle.jl:146-185) on the GPU: returns
-    (rows, cols, vals, X, rho, info) -- the un-merged COO contributions of the Frechet matrix
-    (0-based; rows = 4*ray + component, cols = i + j*N), the traced end states X (num, 4), the
-    Jacobians rho (num, 4, 4) and the per-ray status / step counts."""
+    (FrechetMatrix [device CSR], X (num, 4), rho (num, 4, 4), info)."""
     ctx = ctx or default_context()
     if isinstance(c, SinProd):
         raise RayError("ScatterForwardOperator is defined on gridded media only (NonObstacle.jl:189)")
@@ -288,34 +322,21 @@ def forward_operator_coo(c, m, ext, dt, *, ctx=None):
     nst = np.zeros(num, dtype=np.int32)
     h = C.c_void_p()
     _lib.check(ctx._lib.ray_forward_operator(ctx.handle, med.handle, _ptr(m), num, max(num, 1), float(dt),
+                                             -1.0 if droptol is None else float(droptol),
                                              _ptr(X), max(num, 1), _ptr(rho), _ptr(st), _ptr(nst),
                                              C.byref(h)))
-    try:
-        n = C.c_int64()
-        _lib.check(ctx._lib.ray_frechet_count(h, C.byref(n)))
-        rows = np.zeros(n.value, dtype=np.int64)
-        cols = np.zeros(n.value, dtype=np.int64)
-        vals = np.zeros(n.value, dtype=np.float64)
-        _lib.check(ctx._lib.ray_frechet_export_coo(h, _ptr(rows), _ptr(cols), _ptr(vals), n.value,
-                                                   C.byref(n)))
-    finally:
-        ctx._lib.ray_frechet_destroy(h)
-    return rows, cols, vals, X, rho, {"status": st, "nsteps": nst}
+    return FrechetMatrix(ctx, h), X, rho, {"status": st, "nsteps": nst}
 
 
 def ScatterForwardOperator(c, m, ext, dt, *, ctx=None, info=False, droptol=1e-12):
     """NonObstacle.jl:189-243: returns (M, s).  s[:,1:4], s[:,9] are copied from m (:196) and
     s[:,5:8] are the traced end states (:185); M is the (4 num) x N^2 Frechet matrix as a scipy
-    CSR matrix (rows ray-major like reshape(M, 4num, N^2) at :242, columns i + j*N), duplicates
-    summed by the sparse constructor and entries with |v| <= droptol dropped (droptol!, :242)."""
-    import scipy.sparse as sps
-    rows, cols, vals, X, rho, inf = forward_operator_coo(c, m, ext, dt, ctx=ctx)
+    CSR matrix (rows ray-major like reshape(M, 4num, N^2) at :242, columns i + j*N), assembled on
+    the device with entries |v| <= droptol dropped (droptol!, :242; None keeps every entry)."""
+    F, X, rho, inf = forward_operator_dev(c, m, ext, dt, ctx=ctx, droptol=droptol)
+    M = F.tocsr()
+    F.close()
     num = X.shape[0]
-    N = (c.N if isinstance(c, GridMedium) else np.asarray(c).shape[0])
-    M = sps.coo_matrix((vals, (rows, cols)), shape=(4 * num, N * N)).tocsr()
-    if droptol is not None:
-        M.data[np.abs(M.data) <= droptol] = 0.0
-        M.eliminate_zeros()
     s = np.zeros((num, 9), dtype=np.float64, order="F")
     s[:, 0:4] = np.asarray(m)[:, 0:4]
     s[:, 8] = np.asarray(m)[:, 8]

@@ -59,9 +59,10 @@ SIGNATURES = {
     "ray_shoot_states_dev": [_vp, _vp, C.POINTER(Obstacle), _f64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp],
     "ray_trace_fixed_time": [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _vp, _i64, _vp, _vp],
     "ray_trace_fixed_time_dev": [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _vp, _i64, _vp, _vp],
-    "ray_forward_operator": [_vp, _vp, _vp, _i64, _i64, _f64, _vp, _i64, _vp, _vp, _vp, C.POINTER(_vp)],
-    "ray_frechet_count": [_vp, C.POINTER(_i64)],
-    "ray_frechet_export_coo": [_vp, _vp, _vp, _vp, _i64, C.POINTER(_i64)],
+    "ray_forward_operator": [_vp, _vp, _vp, _i64, _i64, _f64, _f64, _vp, _i64, _vp, _vp, _vp, C.POINTER(_vp)],
+    "ray_frechet_shape": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "ray_frechet_export_csr": [_vp, _vp, _vp, _vp],
+    "ray_frechet_csr_dev": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ray_frechet_destroy": [_vp],
     "ray_misfit": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_misfit_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],

@@ -455,6 +455,17 @@ static void time_end(ray_ctx *ctx, hipEvent_t e0, hipEvent_t e1)
     (void)hipEventRecord(e1, ctx->stream);
     ctx->pending.emplace_back(e0, e1);
 }
+struct TimedSpan {                             // time_begin / time_end that survives early returns
+    ray_ctx *ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool done = false;
+    explicit TimedSpan(ray_ctx *c) : ctx(c) { time_begin(ctx, e0, e1); }
+    void end() { time_end(ctx, e0, e1); done = true; }
+    ~TimedSpan()
+    {
+        if (!done && e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    }
+};
 static void drain_timing(ray_ctx *ctx)
 {
     for (auto &pr : ctx->pending) {
@@ -987,54 +998,56 @@ int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_ho
     return RAY_OK;
 }
 
-// ---- complete forward operator: X, rho, Frechet contributions (NEXT-1) ------------------------------
+// ---- complete forward operator: X, rho, Frechet matrix as device CSR (NEXT-1) ------------------------
 struct ray_frechet {
     ray_ctx *ctx = nullptr;
-    int64_t num = 0;
+    int64_t num = 0, nnz = 0;
     int N = 0;
-    std::vector<int64_t> wave_base;     // slot-row offset per wave
-    std::vector<int32_t> steps;         // steps taken per ray
-    int64_t rows_total = 0;             // slot rows (each 64 lanes wide)
-    int32_t *d_cols = nullptr;
-    double *d_vals = nullptr;
-    std::vector<int32_t> h_cols;        // downloaded lazily by count / export
-    std::vector<double> h_vals;
-    bool on_host = false;
+    int64_t *d_indptr = nullptr;        // 4 num + 1
+    int32_t *d_indices = nullptr;       // nnz, sorted within a row
+    double *d_data = nullptr;           // nnz
 };
 
 int ray_frechet_destroy(ray_frechet *f)
 {
     if (!f) return RAY_OK;
     if (f->ctx) (void)hipSetDevice(f->ctx->device);
-    if (f->d_cols) (void)hipFree(f->d_cols);
-    if (f->d_vals) (void)hipFree(f->d_vals);
+    if (f->d_indptr) (void)hipFree(f->d_indptr);
+    if (f->d_indices) (void)hipFree(f->d_indices);
+    if (f->d_data) (void)hipFree(f->d_data);
     delete f;
     return RAY_OK;
 }
 
-int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld, double dt,
-                         double *X_host, int64_t ldx, double *rho_host, int32_t *status, int32_t *nsteps,
-                         ray_frechet **out)
+// out[0..n] = exclusive prefix sums of in[0..n) on the context's stream; *total_host after a sync
+static int scan_counts(ray_ctx *ctx, const int32_t *in, int64_t n, int64_t *out, int64_t *total_host)
 {
-    if (!out) return fail(RAY_ERR_INVALID, "null out");
-    *out = nullptr;
-    int rc = use(ctx);
-    if (rc) return rc;
-    if ((rc = check_med(ctx, med))) return rc;
-    if (med->kind != kGrid) return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator takes a gridded medium (NonObstacle.jl:189)");
-    if (med->N < 6) return fail(RAY_ERR_INVALID, "the Frechet path needs N >= 6 (hess table, NonObstacle.jl:212)");
-    if (!m_host || !X_host || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
-    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    const int64_t per = 256 * kScanItems;
+    const int64_t nb = (n + per - 1) / per;
+    DevBuf bs, tot;
+    HIPCHK(bs.alloc(sizeof(int64_t) * (size_t)nb));
+    HIPCHK(tot.alloc(sizeof(int64_t)));
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, ctx->stream, in, n, bs.as<int64_t>());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, bs.as<int64_t>(), nb, tot.as<int64_t>());
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, ctx->stream, in, n, bs.as<int64_t>(),
+                       tot.as<int64_t>(), out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(total_host, tot.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld, double dt,
+                                 double droptol, double *X_host, int64_t ldx, double *rho_host, int32_t *status,
+                                 int32_t *nsteps, ray_frechet *f)
+{
     const int max_steps = 1000000;
-    ray_frechet *f = new ray_frechet;
-    f->ctx = ctx; f->num = num; f->N = med->N;
-    f->steps.assign((size_t)num, 0);
-    if (num == 0) { *out = f; return RAY_OK; }
     // slab sizing on the host: a ray takes at most floor(T/dt) + 2 steps (NonObstacle.jl:152-157)
     const int64_t nwave = (num + 63) / 64;
     std::vector<int32_t> cap((size_t)nwave, 0);
-    f->wave_base.assign((size_t)nwave, 0);
+    std::vector<int64_t> wave_base((size_t)nwave, 0);
     int64_t rows = 0;
+    int cap_max = 0;
     for (int64_t w = 0; w < nwave; ++w) {
         double tmax = 0;
         for (int64_t r = w * 64; r < num && r < (w + 1) * 64; ++r) {
@@ -1045,136 +1058,148 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         if (!(tmax > 0)) n = 0;
         if (n > max_steps) n = max_steps;
         cap[(size_t)w] = (int32_t)n;
-        f->wave_base[(size_t)w] = rows;
-        rows += (int64_t)n * 24;
+        if ((int)n > cap_max) cap_max = (int)n;
+        wave_base[(size_t)w] = rows;
+        rows += frechet_entries((int)n);
     }
-    f->rows_total = rows;
+    if (frechet_entries(cap_max) > kMergeMaxEntries)
+        return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator: more than 1364 steps per ray (T/dt); the per-ray merge holds 16384 stencil entries");
     const size_t slots = (size_t)rows * 64;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (slots * 36 + (size_t)num * 256 > free_b) {
-        ray_frechet_destroy(f);
-        return fail(RAY_ERR_NOMEM, "Frechet contribution slab does not fit in device memory (sum of T/dt too large)");
-    }
-    DevBuf dm, dX, drho, dbase, dcap;
+    if (slots * 40 * 2 + (size_t)num * 512 > free_b)
+        return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the stencil slab does not fit in device memory (sum of T/dt too large); split the rays");
+    DevBuf dkeys, dvals, dm, dX, drho, dbase, dcap, ducnt, duoff, ducols, duvals, drowcnt;
     RayOutBufs ob_;
-    hipError_t e = hipMalloc((void **)&f->d_cols, (slots ? slots : 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->d_vals, (slots ? slots : 1) * 4 * sizeof(double));
-    if (e == hipSuccess) e = dm.alloc(sizeof(double) * 9 * (size_t)num);
-    if (e == hipSuccess) e = dX.alloc(sizeof(double) * 4 * (size_t)num);
-    if (e == hipSuccess) e = drho.alloc(sizeof(double) * 16 * (size_t)num);
-    if (e == hipSuccess) e = dbase.alloc(sizeof(int64_t) * (size_t)nwave);
-    if (e == hipSuccess) e = dcap.alloc(sizeof(int32_t) * (size_t)nwave);
-    if (e != hipSuccess) {
-        std::string msg = std::string("ray_forward_operator: ") + hipGetErrorString(e);
-        ray_frechet_destroy(f);
-        return fail(e == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, msg);
-    }
-    if ((rc = ob_.alloc(num)) || (rc = ensure_hess(med))) { ray_frechet_destroy(f); return rc; }
-    bool okc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4) == RAY_OK &&
-               copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1) == RAY_OK;
-    if (okc) okc = hipMemcpyAsync(dbase.p, f->wave_base.data(), sizeof(int64_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-    if (okc) okc = hipMemcpyAsync(dcap.p, cap.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-    if (okc) okc = hipStreamSynchronize(ctx->stream) == hipSuccess;      // cap / wave_base are read by the copies above
-    if (!okc) { ray_frechet_destroy(f); return fail(RAY_ERR_HIP, "ray_forward_operator: upload failed"); }
+    HIPCHK(dkeys.alloc((slots ? slots : 1) * sizeof(int64_t)));
+    HIPCHK(dvals.alloc((slots ? slots : 1) * 4 * sizeof(double)));
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
+    HIPCHK(drho.alloc(sizeof(double) * 16 * (size_t)num));
+    HIPCHK(dbase.alloc(sizeof(int64_t) * (size_t)nwave));
+    HIPCHK(dcap.alloc(sizeof(int32_t) * (size_t)nwave));
+    HIPCHK(ducnt.alloc(sizeof(int32_t) * (size_t)num));
+    HIPCHK(duoff.alloc(sizeof(int64_t) * (size_t)(num + 1)));
+    HIPCHK(drowcnt.alloc(sizeof(int32_t) * 4 * (size_t)num));
+    int rc;
+    if ((rc = ob_.alloc(num)) || (rc = ensure_hess(med))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
+    HIPCHK(hipMemcpyAsync(dbase.p, wave_base.data(), sizeof(int64_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dcap.p, cap.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));           // the host vectors above are read by those copies
+
     FrechetArgs a{};
     a.med = medium_dev(med);
     a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
     a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>();
-    a.cols = f->d_cols; a.vals = f->d_vals;
+    a.keys = dkeys.as<int64_t>(); a.vals = dvals.as<double>();
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
     a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
     a.step_counter = ctx->d_steps;
-    const dim3 grid((unsigned)nwave), block(64);
     const size_t lds = (((size_t)med->N * 8 + 15) & ~(size_t)15);
-    hipEvent_t e0, e1;
-    time_begin(ctx, e0, e1);
-    if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, grid, block, lds, ctx->stream, a);
-    else hipLaunchKernelGGL(k_frechet<kExact>, grid, block, lds, ctx->stream, a);
-    time_end(ctx, e0, e1);
-    e = hipGetLastError();
-    if (e == hipSuccess) {
-        ctx->rays += (uint64_t)num;
-        ctx->launches += 1;
-        rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4);
-        if (!rc && rho_host) e = hipMemcpyAsync(rho_host, drho.p, sizeof(double) * 16 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream);
-        if (!rc && e == hipSuccess) e = hipMemcpyAsync(f->steps.data(), ob_.ns.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream);
-        if (!rc && e == hipSuccess) rc = ob_.fetch(ctx, num, status, nsteps, nullptr);
+    TimedSpan span(ctx);
+    if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(k_frechet<kExact>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
+    HIPCHK(hipGetLastError());
+    // distinct nodes per ray
+    int n2 = 256;
+    while (n2 < frechet_entries(cap_max)) n2 <<= 1;
+    const size_t sort_lds = (size_t)n2 * sizeof(uint64_t);
+    if (sort_lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+    hipLaunchKernelGGL(k_merge_sort, dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
+                       dbase.as<int64_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    int64_t U = 0;
+    if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, duoff.as<int64_t>(), &U))) return rc;
+    HIPCHK(ducols.alloc(sizeof(int32_t) * (size_t)(U ? U : 1)));
+    HIPCHK(duvals.alloc(sizeof(double) * 4 * (size_t)(U ? U : 1)));
+    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, dkeys.as<int64_t>(), dvals.as<double>(),
+                       dbase.as<int64_t>(), ob_.ns.as<int32_t>(), drho.as<double>(), duoff.as<int64_t>(), droptol,
+                       ducols.as<int32_t>(), duvals.as<double>(), drowcnt.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMalloc((void **)&f->d_indptr, sizeof(int64_t) * (size_t)(4 * num + 1)));
+    if ((rc = scan_counts(ctx, drowcnt.as<int32_t>(), 4 * num, f->d_indptr, &f->nnz))) return rc;
+    HIPCHK(hipMalloc((void **)&f->d_indices, sizeof(int32_t) * (size_t)(f->nnz ? f->nnz : 1)));
+    HIPCHK(hipMalloc((void **)&f->d_data, sizeof(double) * (size_t)(f->nnz ? f->nnz : 1)));
+    hipLaunchKernelGGL(k_csr_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, ducols.as<int32_t>(), duvals.as<double>(),
+                       duoff.as<int64_t>(), f->d_indptr, droptol, f->d_indices, f->d_data);
+    HIPCHK(hipGetLastError());
+    span.end();
+    ctx->rays += (uint64_t)num;
+    ctx->launches += 1;
+    if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
+    if (rho_host) HIPCHK(hipMemcpyAsync(rho_host, drho.p, sizeof(double) * 16 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, int64_t num, int64_t ld, double dt,
+                         double droptol, double *X_host, int64_t ldx, double *rho_host, int32_t *status,
+                         int32_t *nsteps, ray_frechet **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med))) return rc;
+    if (med->kind != kGrid) return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator takes a gridded medium (NonObstacle.jl:189)");
+    if (med->N < 6) return fail(RAY_ERR_INVALID, "the Frechet path needs N >= 6 (hess table, NonObstacle.jl:212)");
+    if (!m_host || !X_host || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
+    if (num > 0x7fffffff / 4) return fail(RAY_ERR_INVALID, "too many rays for one call (4 num must fit in int32)");
+    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    ray_frechet *f = new ray_frechet;
+    f->ctx = ctx; f->num = num; f->N = med->N;
+    if (num == 0) {
+        if (hipMalloc((void **)&f->d_indptr, sizeof(int64_t)) != hipSuccess || hipMemset(f->d_indptr, 0, sizeof(int64_t)) != hipSuccess) {
+            ray_frechet_destroy(f);
+            return fail(RAY_ERR_HIP, "ray_forward_operator: allocation failed");
+        }
+        *out = f;
+        return RAY_OK;
     }
-    hipError_t es = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = es;
-    if (rc || e != hipSuccess) {
-        std::string msg = rc ? g_err : std::string("ray_forward_operator: ") + hipGetErrorString(e);
+    rc = forward_operator_impl(ctx, med, m_host, num, ld, dt, droptol, X_host, ldx, rho_host, status, nsteps, f);
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
         ray_frechet_destroy(f);
-        return fail(rc ? rc : RAY_ERR_HIP, msg);
+        return rc;
     }
     *out = f;
     return RAY_OK;
 }
 
-static int frechet_download(ray_frechet *f)
+int ray_frechet_shape(ray_frechet *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
 {
-    if (f->on_host) return RAY_OK;
+    if (!f) return fail(RAY_ERR_INVALID, "null handle");
+    if (n_rows) *n_rows = 4 * f->num;
+    if (n_cols) *n_cols = (int64_t)f->N * f->N;
+    if (nnz) *nnz = f->nnz;
+    return RAY_OK;
+}
+
+int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, double *data)
+{
+    if (!f || !indptr) return fail(RAY_ERR_INVALID, "null argument");
+    if (f->nnz && (!indices || !data)) return fail(RAY_ERR_INVALID, "null indices / data");
     int rc = use(f->ctx);
     if (rc) return rc;
-    const size_t slots = (size_t)f->rows_total * 64;
-    f->h_cols.resize(slots);
-    f->h_vals.resize(slots * 4);
-    if (slots) {
-        HIPCHK(hipMemcpy(f->h_cols.data(), f->d_cols, slots * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(f->h_vals.data(), f->d_vals, slots * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(indptr, f->d_indptr, sizeof(int64_t) * (size_t)(4 * f->num + 1), hipMemcpyDeviceToHost));
+    if (f->nnz) {
+        HIPCHK(hipMemcpy(indices, f->d_indices, sizeof(int32_t) * (size_t)f->nnz, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(data, f->d_data, sizeof(double) * (size_t)f->nnz, hipMemcpyDeviceToHost));
     }
-    f->on_host = true;
     return RAY_OK;
 }
 
-} // extern "C"
-// visits every non-zero contribution (row = 4*ray + r, col = node) in ray order
-template <class F>
-static void frechet_visit(const ray_frechet *f, F &&fn)
+int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data)
 {
-    for (int64_t i = 0; i < f->num; ++i) {
-        const int64_t base = f->wave_base[(size_t)(i >> 6)];
-        const int lane = (int)(i & 63);
-        const int64_t ne = (int64_t)f->steps[(size_t)i] * 24;
-        for (int64_t e = 0; e < ne; ++e) {
-            const size_t s = (size_t)((base + e) * 64 + lane);
-            const int32_t col = f->h_cols[s];
-            if (col < 0) continue;
-            for (int r = 0; r < 4; ++r) {
-                const double v = f->h_vals[s * 4 + r];
-                if (v != 0.0) fn(4 * i + r, (int64_t)col, v);
-            }
-        }
-    }
-}
-
-extern "C" {
-int ray_frechet_count(ray_frechet *f, int64_t *n)
-{
-    if (!f || !n) return fail(RAY_ERR_INVALID, "null argument");
-    int rc = frechet_download(f);
-    if (rc) return rc;
-    int64_t c = 0;
-    frechet_visit(f, [&](int64_t, int64_t, double) { ++c; });
-    *n = c;
-    return RAY_OK;
-}
-
-int ray_frechet_export_coo(ray_frechet *f, int64_t *rows, int64_t *cols, double *vals, int64_t cap, int64_t *n)
-{
-    if (!f || !rows || !cols || !vals || !n) return fail(RAY_ERR_INVALID, "null argument");
-    int rc = frechet_download(f);
-    if (rc) return rc;
-    int64_t c = 0;
-    bool over = false;
-    frechet_visit(f, [&](int64_t r, int64_t col, double v) {
-        if (c < cap) { rows[c] = r; cols[c] = col; vals[c] = v; } else over = true;
-        ++c;
-    });
-    *n = c;
-    if (over) return fail(RAY_ERR_INVALID, "export buffer too small (see ray_frechet_count)");
+    if (!f) return fail(RAY_ERR_INVALID, "null handle");
+    if (indptr) *indptr = f->d_indptr;
+    if (indices) *indices = f->d_indices;
+    if (data) *data = f->d_data;
     return RAY_OK;
 }
 

@@ -1,14 +1,20 @@
 // ray_frechet.h -- NEXT-1 of SURVEY.md section 8f: the Jacobian rho and the Frechet matrix M of
 // ScatterForwardOperator (NonObstacle.jl:6-28 DiscreteHamilton with Hessian, :107-139 dV,
-// :141-187 ChunkProcessing!, :212-218 hess table).
+// :141-187 ChunkProcessing!, :212-218 hess table, :242 sparse + droptol).
 //
 // The reference builds, per ray and per RK4 step, three 4 x N^2 sparse matrices (O(N^2) each) and a
-// dense 4num x N^2 SharedArray.  Here one thread integrates (X, rho) for one ray and EMITS the
-// 12-node stencil contributions Theta = inv(rho) dV w of every quadrature point into a per-wave slab
-// [slot][lane] (coalesced); after the loop it multiplies its own slots by the final rho.  The host
-// (or the caller's sparse constructor, exactly like the reference's sparse() at :137,242) merges
-// duplicate columns.  The reference goes through LAPACK inv / BLAS gemm here, so parity is by
-// tolerance; the X trajectory itself is bit-identical to k_trace (same expressions).
+// dense 4num x N^2 SharedArray that it then compresses.  Here the sparse matrix is built on the device:
+//   k_frechet      one thread integrates (X, rho) of one ray and EMITS the 12-node stencil
+//                  contributions Theta = inv(rho) dV w of every trajectory node into a per-wave slab
+//                  [slot row][lane] (coalesced 8-byte keys, 32-byte values);
+//   k_merge_sort   one workgroup per ray sorts that ray's (node, emission order) keys in LDS and
+//                  ranks the distinct nodes;
+//   k_merge_emit   sums each node's contributions in emission order (the order of the reference's
+//                  Phi += Theta), applies the final rho (M rows = rho * Phi, :184) and counts the
+//                  entries that survive droptol per matrix row;
+//   k_csr_emit     writes the CSR arrays (rows ray-major like reshape(M, 4num, N^2), columns sorted).
+// The reference goes through LAPACK inv / BLAS gemm here, so parity is by tolerance; the X
+// trajectory itself is bit-identical to k_trace (same expressions).
 #pragma once
 #include "ray_device.h"
 
@@ -148,19 +154,24 @@ struct FrechetArgs {
     double dt;
     int max_steps;
     double cease_r;
-    const int64_t *wave_base;   // slot offset of every wave (in units of 64-lane slot rows)
-    const int32_t *wave_cap;    // step capacity of every wave
-    int32_t *cols;              // [slot row][lane] node index (0-based, first index x) or -1
+    const int64_t *wave_base;   // slot-row offset of every wave (rows are 64 lanes wide)
+    const int32_t *wave_cap;    // step capacity of every wave (rows = 12 * (cap + 1))
+    int64_t *keys;              // [slot row][lane] node index (0-based, first index x) or -1
     double *vals;               // [slot row][lane][4]
     double *X;                  // (num, 4) end states
     int64_t ldx;
-    double *rho;                // (num, 16) final Jacobian, row-major; may be null
+    double *rho;                // (num, 16) final Jacobian, row-major
     int32_t *status, *nsteps;
     unsigned long long *step_counter;
 };
 
-// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> slots [e, e+12) of this lane.
-// dV: NonObstacle.jl:107-139.
+constexpr uint64_t kKeyDead = ~0ull;    // sorted key layout: node << 40 | emission index << 20 | rank
+constexpr int kMergeMaxEntries = 16384; // per ray: 128 KiB of LDS keys
+
+__host__ __device__ inline int frechet_entries(int steps) { return steps > 0 ? (steps + 1) * kFrSlotsPerCall : 0; }
+
+// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> slot rows [row0, row0+12) of
+// this lane.  dV: NonObstacle.jl:107-139.
 template <int AR>
 __device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const double rho[16], double w,
                                            bool live, int64_t row0, unsigned lane, int &oob)
@@ -205,7 +216,7 @@ __device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[
             for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 3] * A3) * w;
         }
         const int64_t s = (row0 + k) * 64 + lane;
-        a.cols[s] = (live && ok) ? ni + nj * N : -1;
+        a.keys[s] = (live && ok) ? (int64_t)(ni + nj * N) : (int64_t)-1;
         double2 *dst = reinterpret_cast<double2 *>(a.vals + s * 4);
         dst[0] = make_double2(th[0], th[1]);
         dst[1] = make_double2(th[2], th[3]);
@@ -214,15 +225,17 @@ __device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[
 }
 
 // ChunkProcessing! for one ray per thread                         NonObstacle.jl:146-185
+// The reference adds Theta twice per step (:158 before, :174 after) -- the "after" point of step n and
+// the "before" point of step n+1 are the same (X, rho), so one emission per trajectory node carries
+// both weights (trapezoid rule; the cease term :178 joins the last node's weight).
 template <int AR>
-__global__ __launch_bounds__(256) void k_frechet(const FrechetArgs a)
+__global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < a.num;
     const unsigned lane = threadIdx.x & 63;
     const int64_t wave = r >> 6;
-    // node table into LDS (the look-ups read it from there)
-    {
+    {   // node table into LDS (the look-ups read it from there)
         double *p_lds = reinterpret_cast<double *>(ray_smem);
         for (int k = threadIdx.x; k < a.med.g.N; k += blockDim.x) p_lds[k] = a.med.g.p[k];
         __syncthreads();
@@ -238,17 +251,21 @@ __global__ __launch_bounds__(256) void k_frechet(const FrechetArgs a)
         T = a.m[r + 8 * a.ld];
         if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;
     }
-    double t = 0, dt = a.dt;
-    bool active = valid && t < T;
-    while (__any(active)) {
-        if (it >= cap || it >= a.max_steps) break;
+    double t = 0, dt = a.dt, wp = 0.0;
+    bool active = valid && t < T, fin = false;
+    for (;;) {
+        if (active && (it >= cap || it >= a.max_steps)) { st |= kStStepCap; active = false; fin = true; }
+        const bool anyact = __any(active);
+        if (!anyact && !__any(fin)) break;
         double dtl = 0.0;
         if (active) {
             if ((t + dt) > T) dt = T - t;                                    // :153-156
             t = t + dt;                                                      // :157
             dtl = dt;
         }
-        emit_theta<AR>(a, X, rho, dtl * 0.5, active, base + (int64_t)it * 24, lane, oob);           // :158-159
+        emit_theta<AR>(a, X, rho, wp + dtl * 0.5, active || fin, base + (int64_t)it * kFrSlotsPerCall, lane, oob);
+        fin = false;
+        if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
         double k1[4], H[4], Y[4], accx[4], Jm[16], V[16], R[16], accr[16];
         int o = 0;
@@ -280,9 +297,10 @@ __global__ __launch_bounds__(256) void k_frechet(const FrechetArgs a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) rho[k] = __builtin_fma(accr[k] + V[k], dt6, rho[k]);
         ++it;
-        double w2 = dtl * 0.5;                                               // :174-175
+        wp = 0.0;
         if (active) {
             steps = it;
+            wp = dtl * 0.5;                                                  // :174-175
             const double s = X[0] * X[0] + X[1] * X[1];
             oob |= o | !(s == s);
             const double c2 = a.cease_r * a.cease_r;
@@ -290,37 +308,234 @@ __global__ __launch_bounds__(256) void k_frechet(const FrechetArgs a)
             if (s > c2 * 1.0000000001) out = true;
             else if (s < c2 * 0.9999999999) out = false;
             else out = __builtin_sqrt(s) > a.cease_r;
-            if (out) { w2 = w2 + (T - t); t = t + (T - t); st |= kStCeased; }   // :177-181 (same X, rho: one emission)
+            if (out) { wp = wp + (T - t); t = t + (T - t); st |= kStCeased; }   // :177-181
+            active = t < T;
+            fin = !active;
         }
-        emit_theta<AR>(a, X, rho, w2, active, base + (int64_t)it * 24 - 12, lane, oob);
-        if (active) active = t < T;
     }
-    if (active) st |= kStStepCap;
     if (oob) st |= kStOob;
-    // M rows = rho * Phi (:184): apply the final rho to this ray's own contributions
     if (valid) {
-        for (int e = 0; e < steps * 24; ++e) {
-            const int64_t s = (base + e) * 64 + lane;
-            double2 *p2 = reinterpret_cast<double2 *>(a.vals + s * 4);
-            const double2 lo = p2[0], hi = p2[1];
-            double o4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                o4[i] = ((rho[i * 4] * lo.x + rho[i * 4 + 1] * lo.y) + rho[i * 4 + 2] * hi.x) + rho[i * 4 + 3] * hi.y;
-            p2[0] = make_double2(o4[0], o4[1]);
-            p2[1] = make_double2(o4[2], o4[3]);
-        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) a.X[r + k * a.ldx] = X[k];
-        if (a.rho) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a.rho[r * 16 + k] = rho[k];
-        }
-        if (a.status) a.status[r] = st;
-        if (a.nsteps) a.nsteps[r] = steps;
+        for (int k = 0; k < 16; ++k) a.rho[r * 16 + k] = rho[k];
+        a.status[r] = st;
+        a.nsteps[r] = steps;
     }
     const unsigned wsum = wave_sum((unsigned)steps);
     if (lane == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+}
+
+// ---- merge: distinct nodes of one ray --------------------------------------------------------------
+// One workgroup per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power of
+// two); every entry gets the rank of its node among the ray's distinct nodes and is written back in
+// place as node << 40 | emission << 20 | rank; ucount[ray] = number of distinct nodes.
+__global__ __launch_bounds__(256) void k_merge_sort(int64_t *__restrict__ keys, const int64_t *__restrict__ wave_base,
+                                                    const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount)
+{
+    uint64_t *sk = reinterpret_cast<uint64_t *>(ray_smem);
+    __shared__ int s_cnt[256];
+    const int64_t ray = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ne = frechet_entries(nsteps[ray]);
+    if (ne == 0) {
+        if (tid == 0) ucount[ray] = 0;
+        return;
+    }
+    int n2 = 256;
+    while (n2 < ne) n2 <<= 1;
+    const int64_t base = wave_base[ray >> 6];
+    const int lane = (int)(ray & 63);
+    for (int e = tid; e < n2; e += 256) {
+        int64_t k = -1;
+        if (e < ne) k = keys[(base + e) * 64 + lane];
+        sk[e] = k < 0 ? kKeyDead : ((uint64_t)k << 40 | (uint64_t)e << 20);
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += 256) {
+                const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t x = sk[lo], y = sk[hi];
+                if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+            }
+            __syncthreads();
+        }
+    // rank of each entry's node: heads counted per contiguous chunk, scanned over the 256 threads
+    const int cs = n2 >> 8, e0 = tid * cs;
+    int heads = 0;
+    for (int e = e0; e < e0 + cs; ++e) {
+        const uint64_t k = sk[e];
+        heads += k != kKeyDead && (e == 0 || (sk[e - 1] >> 40) != (k >> 40));
+    }
+    s_cnt[tid] = heads;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    int rank = s_cnt[tid] - heads - 1;              // rank of the last head before this chunk
+    if (tid == 255) ucount[ray] = s_cnt[255];
+    uint64_t outk[1];
+    for (int e = e0; e < e0 + cs; ++e) {
+        const uint64_t k = sk[e];
+        if (k == kKeyDead) { if (e < ne) keys[(base + e) * 64 + lane] = -1; continue; }
+        rank += (e == 0 || (sk[e - 1] >> 40) != (k >> 40));
+        outk[0] = k | (uint64_t)rank;
+        keys[(base + e) * 64 + lane] = (int64_t)outk[0];
+    }
+}
+
+// sums every distinct node's contributions in emission order, applies rho, writes the ray's block row
+// (ucols, uvals[4]) at uoff[ray] and the per-matrix-row entry counts that survive droptol.
+__global__ __launch_bounds__(256) void k_merge_emit(const int64_t *__restrict__ keys, const double *__restrict__ vals,
+                                                    const int64_t *__restrict__ wave_base, const int32_t *__restrict__ nsteps,
+                                                    const double *__restrict__ rho, const int64_t *__restrict__ uoff,
+                                                    double droptol, int32_t *__restrict__ ucols,
+                                                    double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
+{
+    __shared__ int s_rows[4];
+    const int64_t ray = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < 4) s_rows[tid] = 0;
+    __syncthreads();
+    const int ne = frechet_entries(nsteps[ray]);
+    const int64_t base = wave_base[ray >> 6];
+    const int lane = (int)(ray & 63);
+    const int64_t off = uoff[ray];
+    double R[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) R[k] = rho[ray * 16 + k];
+    int cnt[4] = {0, 0, 0, 0};
+    for (int e = tid; e < ne; e += 256) {
+        const uint64_t k = (uint64_t)keys[(base + e) * 64 + lane];
+        if (k == kKeyDead) continue;
+        const uint64_t node = k >> 40;
+        if (e > 0 && ((uint64_t)keys[(base + e - 1) * 64 + lane] >> 40) == node) continue;   // not a head
+        double s[4] = {0, 0, 0, 0};
+        uint64_t k2 = k;
+        int e2 = e;
+        bool first = true;
+        do {
+            const int64_t slot = (base + (int64_t)((k2 >> 20) & 0xFFFFF)) * 64 + lane;
+            const double2 *p2 = reinterpret_cast<const double2 *>(vals + slot * 4);
+            const double2 lo = p2[0], hi = p2[1];
+            if (first) { s[0] = lo.x; s[1] = lo.y; s[2] = hi.x; s[3] = hi.y; first = false; }
+            else { s[0] += lo.x; s[1] += lo.y; s[2] += hi.x; s[3] += hi.y; }                 // Phi += Theta (:159,175)
+            ++e2;
+            k2 = e2 < ne ? (uint64_t)keys[(base + e2) * 64 + lane] : kKeyDead;
+        } while (k2 != kKeyDead && (k2 >> 40) == node);
+        const int64_t u = off + (int64_t)(k & 0xFFFFF);
+        double o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                                       // rho * Phi (:184)
+            o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
+            cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);                   // droptol! (:242)
+        }
+        ucols[u] = (int32_t)node;
+        double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
+        dst[0] = make_double2(o4[0], o4[1]);
+        dst[1] = make_double2(o4[2], o4[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (cnt[i]) atomicAdd(&s_rows[i], cnt[i]);
+    __syncthreads();
+    if (tid < 4) rowcnt[ray * 4 + tid] = s_rows[tid];
+}
+
+// CSR rows 4*ray + r from the ray's block row; one wave per (ray, r), order kept (columns sorted).
+__global__ __launch_bounds__(256) void k_csr_emit(const int32_t *__restrict__ ucols, const double *__restrict__ uvals,
+                                                  const int64_t *__restrict__ uoff, const int64_t *__restrict__ indptr,
+                                                  double droptol, int32_t *__restrict__ indices, double *__restrict__ data)
+{
+    const int64_t ray = blockIdx.x;
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t u0 = uoff[ray], u1 = uoff[ray + 1];
+    int64_t w = indptr[ray * 4 + r];
+    for (int64_t u = u0; u < u1; u += 64) {
+        const bool in = u + lane < u1;
+        const double v = in ? uvals[(u + lane) * 4 + r] : 0.0;
+        const bool keep = in && ((droptol < 0) || (__builtin_fabs(v) > droptol));
+        const uint64_t mask = __ballot(keep);
+        if (keep) {
+            const int64_t pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            indices[pos] = ucols[u + lane];
+            data[pos] = v;
+        }
+        w += __popcll(mask);
+    }
+}
+
+// ---- exclusive scan of int32 counts into int64 offsets (out has n + 1 entries) -----------------------
+constexpr int kScanItems = 16;       // per thread; a block of 256 covers 4096 counts
+
+__global__ __launch_bounds__(256) void k_scan_sums(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ bsum)
+{
+    __shared__ long long s[256];
+    const int64_t b0 = (int64_t)blockIdx.x * 256 * kScanItems + (int64_t)threadIdx.x * kScanItems;
+    long long t = 0;
+    for (int k = 0; k < kScanItems; ++k)
+        if (b0 + k < n) t += in[b0 + k];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void k_scan_blocks(int64_t *__restrict__ bsum, int64_t nb, int64_t *__restrict__ total)
+{
+    __shared__ long long s[256];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < nb; c0 += 256) {
+        const int64_t i = c0 + threadIdx.x;
+        const long long v = i < nb ? bsum[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const long long x = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < nb) bsum[i] = carry + s[threadIdx.x] - v;        // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ bsum,
+                                                    const int64_t *__restrict__ total, int64_t *__restrict__ out)
+{
+    __shared__ long long s[256];
+    const int64_t b0 = (int64_t)blockIdx.x * 256 * kScanItems + (int64_t)threadIdx.x * kScanItems;
+    long long loc[kScanItems], t = 0;
+    for (int k = 0; k < kScanItems; ++k) {
+        loc[k] = t;
+        if (b0 + k < n) t += in[b0 + k];
+    }
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const long long x = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += x;
+        __syncthreads();
+    }
+    const long long pre = bsum[blockIdx.x] + s[threadIdx.x] - t;
+    for (int k = 0; k < kScanItems; ++k)
+        if (b0 + k < n) out[b0 + k] = pre + loc[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
 } // namespace ray

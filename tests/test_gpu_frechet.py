@@ -52,6 +52,13 @@ def test_forward_operator_droptol_and_shape(ctx, orc):
     M, s = ray_amd.ScatterForwardOperator(c, m, 1.5, 5e-2, ctx=ctx)
     assert M.shape == (4 * m.shape[0], 41 * 41)
     assert M.nnz > 0 and np.all(np.abs(M.data) > 1e-12)
+    assert M.has_canonical_format                             # sorted columns, no duplicates
+    Mall, _ = ray_amd.ScatterForwardOperator(c, m, 1.5, 5e-2, ctx=ctx, droptol=None)
+    keep = np.abs(Mall.data) > 1e-12                          # droptol! (:242) is a per-entry filter
+    assert M.nnz == int(keep.sum()) and np.array_equal(M.data, Mall.data[keep])
+    # the four rows of a ray share one stencil pattern before the drop
+    ip = Mall.indptr
+    assert np.array_equal(Mall.indices[ip[0]:ip[1]], Mall.indices[ip[1]:ip[2]])
     assert np.array_equal(s[:, 0:4], m[:, 0:4]) and np.array_equal(s[:, 8], m[:, 8])
 
 
@@ -95,3 +102,25 @@ def test_forward_operator_after_update(ctx, orc):
     Xo, _, Mo, _, _ = orc.forward_operator(orc.GridTables(c2, 1.5, 1), m, 5e-2)
     assert np.array_equal(s[:, 4:8], Xo)
     assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+
+
+def test_forward_operator_golden(ctx, arith):
+    """against tests/golden/frechet_n31_ns4_nd8.npz (made by oracle/gen_golden.py from the
+    independent Python restatement; includes the cease branch)."""
+    import ray_amd
+    from conftest import golden
+    g = golden("frechet_n31_ns4_nd8.npz")
+    N = int(g["N"])
+    m = np.zeros((g["rows"].shape[0], 9), order="F")
+    m[:, 0:4] = g["rows"]
+    m[:, 8] = g["T"]
+    M, s, info = ray_amd.ScatterForwardOperator(np.asfortranarray(g["c"]), m, float(g["ext"]),
+                                                float(g["trace_dt"]), ctx=ctx, info=True, droptol=None)
+    Mg = np.zeros((4 * m.shape[0], N * N))
+    Mg[g["M_rows"], g["M_cols"]] = g["M_vals"]
+    if arith == 0:
+        assert np.array_equal(s[:, 4:8], g["X"])
+    else:
+        assert np.max(np.abs(s[:, 4:8] - g["X"])) <= 1e-10
+    assert np.max(np.abs(info["rho"] - g["rho"])) <= MTOL * np.max(np.abs(g["rho"]))
+    assert np.max(np.abs(M.toarray() - Mg)) <= MTOL * np.max(np.abs(Mg))
