@@ -176,6 +176,31 @@ int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, do
 int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data);
 int ray_frechet_destroy(ray_frechet *f);
 
+/* ---- passes of the reconstruction loop over M (NonObstacle.jl:340-367; SURVEY.md section 8f NEXT-2) ----
+ * The normal-equation solve A\b (CHOLMOD, :353-356) stays with the caller; these are the O(nnz)
+ * passes around it, run on the device CSR.  Vector lengths: fidelity / x / b = N^2 (node order
+ * i + j*N), v / mismatch / y / residual = 4 num (ray-major, like `mismatch` at :336), dofs / ray_mask =
+ * num.  ray_mask[j] != 0 selects the four rows of ray j (the reference's `order`, :345-349; NULL = all).
+ *   dofs[j]   = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])                     (:340-342)
+ *   b         = M[order,:]' * v[order]            (take b[Idx] for :354; fp64 atomics: 1e-12)
+ *   y         = M * x
+ *   fidelity_update: residual = |M[k,:] x - mismatch[k]| on the selected rows (0 elsewhere; x must be
+ *               zero outside Idx to reproduce :359), and where residual < rejection
+ *               fidelity[find(M[k,:])] = max(fidelity, 1 - decay*residual)           (:362-367)
+ * `_dev` forms take device pointers and are asynchronous on the context's stream.              */
+int ray_frechet_dofs(ray_frechet *f, const double *fidelity, double *dofs);
+int ray_frechet_dofs_dev(ray_frechet *f, const double *fidelity_dev, double *dofs_dev);
+int ray_frechet_matvec(ray_frechet *f, const double *x, double *y);
+int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev);
+int ray_frechet_matvec_t(ray_frechet *f, const double *v, const uint8_t *ray_mask, double *b);
+int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t *ray_mask_dev, double *b_dev);
+int ray_frechet_fidelity_update(ray_frechet *f, const double *x, const double *mismatch,
+                                const uint8_t *ray_mask, double rejection, double decay,
+                                double *fidelity, double *residual);
+int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const double *mismatch_dev,
+                                    const uint8_t *ray_mask_dev, double rejection, double decay,
+                                    double *fidelity_dev, double *residual_dev);
+
 /* ---- misfit (NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252) ------------------
  * out[0] = sum_r,k (m[r,4+k]-obs[r,4+k])^2, out[1] = sum_r,k m[r,4+k]^2  (objective =
  * sqrt(out[0]/out[1])); mask[r] = |m[r,5:8]-obs[r,5:8]| / |m[r,5:8]| < perc_thresh;

@@ -197,3 +197,43 @@ def misfit(m, obs, thresh=0.2):
     lib().orc_misfit(_dp(m), _dp(obs), C.c_int64(num), C.c_int64(num), _dp(mism), _dp(out),
                      _dp(mask), C.c_double(thresh))
     return mism, out, mask
+
+
+# ---- NEXT-2: the reconstruction loop's passes over M (NonObstacle.jl:340-367), numpy restatement --------
+def loop_dofs(M, fidelity):
+    """dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])  (NonObstacle.jl:340-342).
+    M: scipy CSR (4num, N^2) with explicit zeros already dropped."""
+    M = M.tocsr()
+    out = np.zeros(M.shape[0] // 4)
+    for j in range(out.size):
+        cols = M.indices[M.indptr[4 * j]:M.indptr[4 * j + 1]]
+        out[j] = cols.size - fidelity[cols].sum()
+    return out
+
+
+def loop_order(dofs, rank_thres):
+    """perm / trunc / order (NonObstacle.jl:345-349) -> (ray mask, 0-based row list in the reference's order)."""
+    perm = np.argsort(dofs, kind="stable")
+    trunc = np.searchsorted(dofs[perm], rank_thres, side="right")
+    rays = perm[:trunc]
+    rows = (4 * rays[:, None] + np.arange(4)[None, :]).reshape(-1)
+    mask = np.zeros(dofs.size, dtype=np.uint8)
+    mask[rays] = 1
+    return mask, rows
+
+
+def loop_gradient(M, mismatch, rows):
+    """b = M[order,:]' * mismatch[order] over all N^2 columns (NonObstacle.jl:351,354 take [Idx])."""
+    return M.tocsr()[rows, :].T @ mismatch[rows]
+
+
+def loop_fidelity(M, correction, mismatch, rows, fidelity, rejection, decay):
+    """residual and fidelity update (NonObstacle.jl:359-367), sequential like the reference."""
+    M = M.tocsr()
+    fid = fidelity.copy()
+    residual = np.abs(M[rows, :] @ correction - mismatch[rows])
+    for k, row in enumerate(rows):
+        if residual[k] < rejection:
+            ids = M.indices[M.indptr[row]:M.indptr[row + 1]]
+            fid[ids] = np.maximum(fid[ids], 1 - decay * residual[k])
+    return fid, residual

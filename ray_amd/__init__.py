@@ -295,6 +295,47 @@ class FrechetMatrix:
         _lib.check(self.ctx._lib.ray_frechet_csr_dev(self.handle, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    # -- the reconstruction loop's passes over M (NonObstacle.jl:340-367), on the device -----------
+    def _vec(self, a, n, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype).reshape(-1)
+        if a.size != n:
+            raise ValueError(f"expected a vector of length {n}, got {a.size}")
+        return a
+
+    def dofs(self, fidelity):
+        """dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])  (NonObstacle.jl:340-342)."""
+        fid = self._vec(fidelity, self.shape[1])
+        out = np.zeros(self.shape[0] // 4)
+        _lib.check(self.ctx._lib.ray_frechet_dofs(self.handle, _ptr(fid), _ptr(out)))
+        return out
+
+    def matvec(self, x):
+        x = self._vec(x, self.shape[1])
+        y = np.zeros(self.shape[0])
+        _lib.check(self.ctx._lib.ray_frechet_matvec(self.handle, _ptr(x), _ptr(y)))
+        return y
+
+    def rmatvec(self, v, ray_mask=None):
+        """b = M[order,:]' v[order] with `order` = the four rows of every ray with ray_mask != 0
+        (NonObstacle.jl:349,354; take b[Idx])."""
+        v = self._vec(v, self.shape[0])
+        mk = None if ray_mask is None else self._vec(ray_mask, self.shape[0] // 4, np.uint8)
+        b = np.zeros(self.shape[1])
+        _lib.check(self.ctx._lib.ray_frechet_matvec_t(self.handle, _ptr(v), _ptr(mk) if mk is not None else None, _ptr(b)))
+        return b
+
+    def fidelity_update(self, correction, mismatch, fidelity, rejection, decay, ray_mask=None):
+        """NonObstacle.jl:359-367: returns (fidelity_new, residual); residual is 0 on unselected rows."""
+        x = self._vec(correction, self.shape[1])
+        mm = self._vec(mismatch, self.shape[0])
+        fid = self._vec(fidelity, self.shape[1]).copy()
+        mk = None if ray_mask is None else self._vec(ray_mask, self.shape[0] // 4, np.uint8)
+        res = np.zeros(self.shape[0])
+        _lib.check(self.ctx._lib.ray_frechet_fidelity_update(self.handle, _ptr(x), _ptr(mm),
+                                                             _ptr(mk) if mk is not None else None,
+                                                             float(rejection), float(decay), _ptr(fid), _ptr(res)))
+        return fid, res
+
     def close(self):
         if self.handle:
             self.ctx._lib.ray_frechet_destroy(self.handle)

@@ -64,6 +64,14 @@ SIGNATURES = {
     "ray_frechet_export_csr": [_vp, _vp, _vp, _vp],
     "ray_frechet_csr_dev": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ray_frechet_destroy": [_vp],
+    "ray_frechet_dofs": [_vp, _vp, _vp],
+    "ray_frechet_dofs_dev": [_vp, _vp, _vp],
+    "ray_frechet_matvec": [_vp, _vp, _vp],
+    "ray_frechet_matvec_dev": [_vp, _vp, _vp],
+    "ray_frechet_matvec_t": [_vp, _vp, _vp, _vp],
+    "ray_frechet_matvec_t_dev": [_vp, _vp, _vp, _vp],
+    "ray_frechet_fidelity_update": [_vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
+    "ray_frechet_fidelity_update_dev": [_vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
     "ray_misfit": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_misfit_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_ctx_enable_timing": [_vp, C.c_int],

@@ -1203,6 +1203,145 @@ int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **
     return RAY_OK;
 }
 
+// ---- NEXT-2: passes of the reconstruction loop over M (NonObstacle.jl:340-367) ------------------------
+static int check_frechet(ray_frechet *f)
+{
+    if (!f) return fail(RAY_ERR_INVALID, "null handle");
+    return use(f->ctx);
+}
+static unsigned wave_rows_grid(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+
+int ray_frechet_dofs_dev(ray_frechet *f, const double *fidelity_dev, double *dofs_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!fidelity_dev || !dofs_dev) return fail(RAY_ERR_INVALID, "null argument");
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_dofs, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr, f->d_indices,
+                       fidelity_dev, f->num, dofs_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x_dev || !y_dev) return fail(RAY_ERR_INVALID, "null argument");
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_matvec, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
+                       f->d_indices, f->d_data, x_dev, 4 * f->num, y_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t *ray_mask_dev, double *b_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!v_dev || !b_dev) return fail(RAY_ERR_INVALID, "null argument");
+    HIPCHK(hipMemsetAsync(b_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_matvec_t, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
+                       f->d_indices, f->d_data, v_dev, ray_mask_dev, 4 * f->num, b_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const double *mismatch_dev,
+                                    const uint8_t *ray_mask_dev, double rejection, double decay,
+                                    double *fidelity_dev, double *residual_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x_dev || !mismatch_dev || !fidelity_dev) return fail(RAY_ERR_INVALID, "null argument");
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_fidelity, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
+                       f->d_indices, f->d_data, x_dev, mismatch_dev, ray_mask_dev, rejection, decay, 4 * f->num,
+                       fidelity_dev, residual_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+// host-pointer forms: stage, run, fetch
+struct Staged {
+    DevBuf d;
+    int up(ray_ctx *ctx, const void *src, size_t bytes)
+    {
+        HIPCHK(d.alloc(bytes));
+        if (src && bytes) HIPCHK(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RAY_OK;
+    }
+    int down(ray_ctx *ctx, void *dst, size_t bytes)
+    {
+        if (dst && bytes) HIPCHK(hipMemcpyAsync(dst, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return RAY_OK;
+    }
+};
+
+int ray_frechet_dofs(ray_frechet *f, const double *fidelity, double *dofs)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!fidelity || !dofs) return fail(RAY_ERR_INVALID, "null argument");
+    const size_t n2 = (size_t)f->N * f->N;
+    Staged fi, out;
+    if ((rc = fi.up(f->ctx, fidelity, n2 * 8)) || (rc = out.up(f->ctx, nullptr, (size_t)f->num * 8))) return rc;
+    if ((rc = ray_frechet_dofs_dev(f, fi.d.as<double>(), out.d.as<double>()))) return rc;
+    if ((rc = out.down(f->ctx, dofs, (size_t)f->num * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+int ray_frechet_matvec(ray_frechet *f, const double *x, double *y)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x || !y) return fail(RAY_ERR_INVALID, "null argument");
+    Staged xi, out;
+    if ((rc = xi.up(f->ctx, x, (size_t)f->N * f->N * 8)) || (rc = out.up(f->ctx, nullptr, (size_t)f->num * 32))) return rc;
+    if ((rc = ray_frechet_matvec_dev(f, xi.d.as<double>(), out.d.as<double>()))) return rc;
+    if ((rc = out.down(f->ctx, y, (size_t)f->num * 32))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+int ray_frechet_matvec_t(ray_frechet *f, const double *v, const uint8_t *ray_mask, double *b)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!v || !b) return fail(RAY_ERR_INVALID, "null argument");
+    Staged vi, mi, out;
+    if ((rc = vi.up(f->ctx, v, (size_t)f->num * 32)) || (rc = out.up(f->ctx, nullptr, (size_t)f->N * f->N * 8))) return rc;
+    if (ray_mask && (rc = mi.up(f->ctx, ray_mask, (size_t)f->num))) return rc;
+    if ((rc = ray_frechet_matvec_t_dev(f, vi.d.as<double>(), ray_mask ? mi.d.as<uint8_t>() : nullptr, out.d.as<double>()))) return rc;
+    if ((rc = out.down(f->ctx, b, (size_t)f->N * f->N * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+int ray_frechet_fidelity_update(ray_frechet *f, const double *x, const double *mismatch, const uint8_t *ray_mask,
+                                double rejection, double decay, double *fidelity, double *residual)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x || !mismatch || !fidelity) return fail(RAY_ERR_INVALID, "null argument");
+    const size_t n2 = (size_t)f->N * f->N;
+    Staged xi, mm, mi, fi, res;
+    if ((rc = xi.up(f->ctx, x, n2 * 8)) || (rc = mm.up(f->ctx, mismatch, (size_t)f->num * 32)) ||
+        (rc = fi.up(f->ctx, fidelity, n2 * 8)))
+        return rc;
+    if (ray_mask && (rc = mi.up(f->ctx, ray_mask, (size_t)f->num))) return rc;
+    if (residual && (rc = res.up(f->ctx, nullptr, (size_t)f->num * 32))) return rc;
+    if ((rc = ray_frechet_fidelity_update_dev(f, xi.d.as<double>(), mm.d.as<double>(), ray_mask ? mi.d.as<uint8_t>() : nullptr,
+                                              rejection, decay, fi.d.as<double>(), residual ? res.d.as<double>() : nullptr)))
+        return rc;
+    if ((rc = fi.down(f->ctx, fidelity, n2 * 8))) return rc;
+    if (residual && (rc = res.down(f->ctx, residual, (size_t)f->num * 32))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
 // ---- misfit ---------------------------------------------------------------------------------------
 int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
                    double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev)

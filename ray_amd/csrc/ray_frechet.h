@@ -538,4 +538,91 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t *__restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
+// ---- NEXT-2: the reconstruction loop's passes over M (NonObstacle.jl:340-367) on the device CSR ----------
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])        NonObstacle.jl:340-342; one wave per ray
+__global__ __launch_bounds__(256) void k_csr_dofs(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                  const double *__restrict__ fidelity, int64_t num, double *__restrict__ dofs)
+{
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= num) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = indptr[ray * 4], e = indptr[ray * 4 + 1];
+    double s = 0;
+    for (int64_t k = b + lane; k < e; k += 64) s += fidelity[indices[k]];
+    s = wave_sum_f64(s);
+    if (lane == 0) dofs[ray] = (double)(e - b) - s;
+}
+
+// y = M x; one wave per row
+__global__ __launch_bounds__(256) void k_csr_matvec(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                    const double *__restrict__ data, const double *__restrict__ x,
+                                                    int64_t nrows, double *__restrict__ y)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0;
+    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
+    s = wave_sum_f64(s);
+    if (lane == 0) y[row] = s;
+}
+
+// b += M' (mask .* v): the rows of the selected rays scattered into b (NonObstacle.jl:354); fp64 atomics
+__global__ __launch_bounds__(256) void k_csr_matvec_t(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const double *__restrict__ data, const double *__restrict__ v,
+                                                      const uint8_t *__restrict__ ray_mask, int64_t nrows, double *__restrict__ b)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    if (ray_mask && !ray_mask[row >> 2]) return;
+    const int lane = threadIdx.x & 63;
+    const double vr = v[row];
+    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) unsafeAtomicAdd(&b[indices[k]], data[k] * vr);
+}
+
+__device__ __forceinline__ void atomic_max_f64(double *addr, double v)
+{
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);
+    unsigned long long old = *a;
+    while (__longlong_as_double((long long)old) < v) {
+        const unsigned long long seen = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+        if (seen == old) break;
+        old = seen;
+    }
+}
+
+// residual[k] = |M[k,:] x - mismatch[k]| for the rows of the selected rays; where residual < rejection,
+// fidelity[find(M[k,:])] = max(fidelity, 1 - decay * residual)     NonObstacle.jl:359-367
+__global__ __launch_bounds__(256) void k_csr_fidelity(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                      const double *__restrict__ data, const double *__restrict__ x,
+                                                      const double *__restrict__ mismatch, const uint8_t *__restrict__ ray_mask,
+                                                      double rejection, double decay, int64_t nrows,
+                                                      double *__restrict__ fidelity, double *__restrict__ residual)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    if (ray_mask && !ray_mask[row >> 2]) {
+        if (residual && lane == 0) residual[row] = 0.0;
+        return;
+    }
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    double s = 0;
+    for (int64_t k = b + lane; k < e; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
+    s = wave_sum_f64(s);
+    const double res = __builtin_fabs(s - mismatch[row]);
+    if (residual && lane == 0) residual[row] = res;
+    if (res < rejection) {
+        const double f = 1 - decay * res;
+        for (int64_t k = b + lane; k < e; k += 64) atomic_max_f64(&fidelity[indices[k]], f);
+    }
+}
+
 } // namespace ray

@@ -124,3 +124,47 @@ def test_forward_operator_golden(ctx, arith):
         assert np.max(np.abs(s[:, 4:8] - g["X"])) <= 1e-10
     assert np.max(np.abs(info["rho"] - g["rho"])) <= MTOL * np.max(np.abs(g["rho"]))
     assert np.max(np.abs(M.toarray() - Mg)) <= MTOL * np.max(np.abs(Mg))
+
+
+def test_reconstruction_loop_passes(ctx, orc):
+    """SURVEY.md section 8f NEXT-2 (NonObstacle.jl:340-367): dofs, b = M' mismatch over the selected rays,
+    residual + fidelity update, on the device CSR against the numpy restatement in oracle/orc.py."""
+    import ray_amd
+    N = 61
+    c, tab, m = _data(orc, N, 6, 24, 1)
+    c0 = np.asfortranarray(1.0 + 0.6 * (c - 1.0))                  # the iterate differs from the truth
+    F, X, rho, info = ray_amd.forward_operator_dev(c0, m, 1.5, 5e-2, ctx=ctx)
+    M = F.tocsr()
+    num = m.shape[0]
+    mismatch = (m[:, 4:8] - X).reshape(-1)                        # (:336) ray-major
+    rng = np.random.default_rng(5)
+    fidelity = rng.uniform(0, 1, N * N) * (rng.uniform(0, 1, N * N) < 0.5)
+    # dofs (:340-342)
+    d_ref = orc.loop_dofs(M, fidelity)
+    d = F.dofs(fidelity)
+    assert np.max(np.abs(d - d_ref)) <= 1e-12 * np.max(np.abs(d_ref))
+    # order / gradient (:345-354)
+    mask, rows = orc.loop_order(d_ref, np.median(d_ref))
+    assert 0 < mask.sum() < num
+    b_ref = orc.loop_gradient(M, mismatch, rows)
+    b = F.rmatvec(mismatch, mask)
+    assert np.max(np.abs(b - b_ref)) <= 1e-12 * np.max(np.abs(b_ref))
+    b_all = F.rmatvec(mismatch)
+    assert np.max(np.abs(b_all - M.T @ mismatch)) <= 1e-12 * np.max(np.abs(b_all))
+    # M x
+    x = rng.normal(size=N * N) * 1e-2
+    assert np.max(np.abs(F.matvec(x) - M @ x)) <= 1e-12 * np.max(np.abs(M @ x))
+    # residual + fidelity (:359-367): thresholds chosen so that some rows pass and some do not
+    res_all = np.abs(M @ x - mismatch)
+    rejection = float(np.median(res_all[rows]))
+    fid_ref, res_ref = orc.loop_fidelity(M, x, mismatch, rows, fidelity, rejection, 0.5)
+    fid, res = F.fidelity_update(x, mismatch, fidelity, rejection, 0.5, mask)
+    assert np.max(np.abs(res[rows] - res_ref)) <= 1e-12 * np.max(res_ref)
+    unsel = np.setdiff1d(np.arange(4 * num), rows)
+    assert not res[unsel].any()
+    # rows within rounding of the threshold may flip; none here by construction of the margin check
+    margin = np.min(np.abs(res_ref - rejection))
+    assert margin > 1e-12
+    assert np.array_equal(fid, fid_ref)                            # max is order-independent: exact
+    assert (fid != fidelity).any()
+    F.close()
