@@ -6,7 +6,7 @@
 #
 #   ScatterRelation(c, ∇c, ns, nd, dt, dir)               NonObstacle.jl:54
 #   ScatterRelationObstacle(c, ∇c, ob, ∇ob, ns, nd, dt)   Obstacle.jl:11
-#   ScatterForwardOperator(c, m, ext, dt)                  NonObstacle.jl:189   (X part; M = NEXT-1)
+#   ScatterForwardOperator(c, m, ext, dt)                  NonObstacle.jl:189   (s and sparse M)
 #   NonReflectionTrace(c, m, ext, dt)                      Obstacle.jl:275
 #
 # Only `ccall`; no AMDGPU.jl, no CUDA shims, no CPU fallback (a missing library is an error).
@@ -19,6 +19,7 @@
 # drive.  INTEGRATION.md lists the three lines a maintainer changes in the demo scripts.
 module RayAMD
 
+using SparseArrays
 using SharedArrays   # NonObstacleReconstruction requires m::SharedArray{Float64,2} (NonObstacle.jl:283)
 
 export SinProd, Circle, smooth_demo, obstacle_demo,
@@ -149,13 +150,36 @@ function trace(c::Matrix{Float64}, m::AbstractMatrix{Float64}, ext::Float64, dt:
     X
 end
 
-# ---- NonObstacle.jl:189: (M, s).  s[:,1:4], s[:,9] copied from m (:196), s[:,5:8] traced (:185). ------------
-# M (Fréchet matrix, :149-184,242) is the NEXT-1 row of SURVEY.md §8f: `nothing` in this round.
-function ScatterForwardOperator(c::Matrix{Float64}, m, ext::Float64, dt::Float64)
-    s = SharedArray{Float64}((size(m, 1), 9))
+# ---- NonObstacle.jl:189: (M, s).  s[:,1:4], s[:,9] copied from m (:196), s[:,5:8] traced (:185); ------------
+# M = droptol!(sparse(M), 1e-12) (:242), assembled sparse on the GPU and handed over as CSR, i.e. the CSC
+# arrays of M' -- one transpose gives the reference's SparseMatrixCSC.
+function ScatterForwardOperator(c::Matrix{Float64}, m, ext::Float64, dt::Float64; droptol::Float64 = 1e-12)
+    num = size(m, 1); N = size(c, 1)
+    mm = Matrix{Float64}(m)
+    X = Matrix{Float64}(undef, num, 4)
+    s = SharedArray{Float64}((num, 9))
     s[:, 1:4] = m[:, 1:4]; s[:, 9] = m[:, 9]
-    s[:, 5:8] = trace(c, m, ext, dt, TRACE_SHORTEN_CEASE)
-    nothing, s
+    local M
+    with_medium(c, ext) do med
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ray_forward_operator, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cdouble, Cdouble, Ptr{Cdouble}, Int64,
+                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                    context(), med, mm, num, max(num, 1), dt, droptol, X, max(num, 1), C_NULL, C_NULL, C_NULL, h))
+        try
+            nr = Ref{Int64}(0); nc = Ref{Int64}(0); nz = Ref{Int64}(0)
+            check(ccall((:ray_frechet_shape, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), h[], nr, nc, nz))
+            indptr = Vector{Int64}(undef, nr[] + 1); indices = Vector{Int32}(undef, nz[]); data = Vector{Float64}(undef, nz[])
+            check(ccall((:ray_frechet_export_csr, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Cdouble}),
+                        h[], indptr, indices, data))
+            Mt = SparseMatrixCSC(Int(nc[]), Int(nr[]), indptr .+ 1, Int64.(indices) .+ 1, data)   # = M'
+            M = copy(transpose(Mt))
+        finally
+            ccall((:ray_frechet_destroy, LIB), Cint, (Ptr{Cvoid},), h[])
+        end
+    end
+    s[:, 5:8] = X
+    M, s
 end
 
 # ---- Obstacle.jl:275 --------------------------------------------------------------------------------------
