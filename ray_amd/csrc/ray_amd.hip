@@ -153,17 +153,26 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
         }
         if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;    // NaN position: see cell_of()
     }
+    // pre-step state (NonObstacle.jl:71 `prev`) of every live lane, parked in LDS each step so that
+    // the step can update X in place; a lane stops writing when it exits, which leaves its pre-exit
+    // state there for the deferred bisection
+    __shared__ double2 s_park[2 * 256];
     const double dt = a.dt;
+    double dtl = valid ? dt : 0.0; // this lane's step: 0 once it has left (or is padding)
     double tw = 0, t = 0;          // tw: wave-uniform clock; t: this lane's, latched at its exit
     int it = 0, steps = 0;         // it: wave-uniform step count
     int nref = 0, rfl = 0;
     bool active = valid;
-    while (__any(active)) {
-        if (it >= a.max_steps) break;                       // wave-uniform; live lanes get STEP_CAP below
+    // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
+    if (__any(active) && a.max_steps > 0) do {
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
+        if (active) {
+            s_park[threadIdx.x] = make_double2(X[0], X[1]);
+            s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
+        }
         double Xn[4];
         int o = 0;
-        rk4<MED, AR, 0>(a.med, acc, X, Xn, active ? dt : 0.0, o);
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, o);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
@@ -171,11 +180,7 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
         if (active) {
             oob |= o | !(s == s);
             if (s >= 1.0) {
-                // pre-step state (NonObstacle.jl:71 `prev`) parked in the output row until the
-                // deferred bisection below picks it up
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];
-                t = tw; steps = it;
+                t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
             } else if (OB == kObCircle) {
                 if (ob_val(a.ob_r0, Xn[0], Xn[1]) <= 0 && rfl == 0) {            // Obstacle.jl:69-91
@@ -208,13 +213,15 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-    }
+    } while (__any(active) && it < a.max_steps);
     if (active) { st |= kStStepCap; t = tw; steps = it; }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
         double lo = 0, hi = 1, mid = 0.5, E[4], e, P[4];
         int ib = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) P[k] = a.m[r + (4 + k) * a.ld];
+        {
+            const double2 p01 = s_park[threadIdx.x], p23 = s_park[256 + threadIdx.x];
+            P[0] = p01.x; P[1] = p01.y; P[2] = p23.x; P[3] = p23.y;
+        }
         lerp4(E, P, X, mid);
         e = norm2(E[0], E[1]) - 1;
         while (__builtin_fabs(e) > 1e-15) {
