@@ -103,7 +103,7 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 //    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
 //    parked in the output row meanwhile.
 template <int MED, int OB, int AR>
-__global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, 5) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
@@ -164,21 +164,21 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
     int nref = 0, rfl = 0;
     bool active = valid;
     // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
-    if (__any(active) && a.max_steps > 0) do {
+    if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {   // (live lanes <=> dtl != 0)
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
         if (active) {
             s_park[threadIdx.x] = make_double2(X[0], X[1]);
             s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
         }
         double Xn[4];
-        int o = 0;
+        OobMax o = 0;
         rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, o);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
-            oob |= o | !(s == s);
+            oob |= (MED == kGrid ? oob_hit(a.med.g, o) : 0) | !(s == s);
             if (s >= 1.0) {
                 t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_shoot(const ShootArgs a)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-    } while (__any(active) && it < a.max_steps);
+    } while (__builtin_amdgcn_ballot_w64(dtl != 0.0) != 0 && it < a.max_steps);
     if (active) { st |= kStStepCap; t = tw; steps = it; }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
         double lo = 0, hi = 1, mid = 0.5, E[4], e, P[4];
@@ -291,13 +291,13 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
             dtl = dt;
         }
         double Xn[4];
-        int o = 0;
+        OobMax o = 0;
         rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, o);
         ++it;
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
             steps = it;
-            oob |= o | !(s == s);
+            oob |= oob_hit(a.med.g, o) | !(s == s);
             if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
                 // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
                 // threshold; outside it the squared comparison decides with certainty.

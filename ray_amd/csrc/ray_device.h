@@ -54,12 +54,15 @@ __device__ __forceinline__ double div6(double a)
 //   [ p[0..N) node coordinates | per wave: 64 x 96-byte record slots | per wave: 64 cell ids ]
 // The node table leaves the vector-memory path entirely; the record slots are the landing zone of
 // the wave-cooperative record fetch below.
-constexpr int kRunSlots = 64;                       // record slots per wave: one per lane, never overflows
-constexpr int kPasses = (kRunSlots * 6 + 63) / 64;  // global_load_lds passes to fill them all (5)
-constexpr int kWaveLdsBytes = kRunSlots * 96 + kRunSlots * 4;
+constexpr int kRunSlots = 42;                       // record slots per wave; wider fans take the per-lane path
+constexpr int kPasses = 4;                          // global_load_lds passes that fill them (4 x 1 KiB >= 42 x 96 B)
+constexpr int kWaveSlotBytes = kPasses * 1024;
+constexpr int kWaveLdsBytes = kWaveSlotBytes + 64 * 4;
 
 struct GridAcc {
     unsigned wrec;           // LDS byte offset of this wave's record slots
+    unsigned wrec_v;         // the same in a VGPR (addend of the per-lane slot address mad)
+    double nb_v;             // g.nb in VGPRs: fma(x, rh, nb) may read one SGPR operand only
     unsigned wcells;         // LDS byte offset of this wave's cell-id slots
     unsigned lane;
     unsigned role_run4[3];   // loader role slot s (shift 0,4,2): 4 * ((lane + shift) / 6) ...
@@ -83,9 +86,12 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     const unsigned poff = ((unsigned)g.N * 8u + 15u) & ~15u;
     // wave-uniform by construction; readfirstlane tells the compiler so (LDS bases live in SGPRs)
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    a.wrec = poff + wave * (kRunSlots * 96);
-    a.wcells = poff + nw * (kRunSlots * 96) + wave * (kRunSlots * 4);
+    a.wrec = poff + wave * kWaveSlotBytes;
+    a.wcells = poff + nw * kWaveSlotBytes + wave * (64 * 4);
     a.lane = threadIdx.x & 63;
+    a.wrec_v = a.wrec;
+    a.nb_v = g.nb;
+    asm volatile("" : "+v"(a.wrec_v), "+v"(a.nb_v));       // opaque: not re-materialised from SGPRs per use
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
         const unsigned v = a.lane + (sl == 0 ? 0u : sl == 1 ? 4u : 2u), run = (v * 171u) >> 10;   // v / 6
@@ -93,7 +99,7 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
         a.role_poff[sl] = (v - run * 6u) * 16u;
     }
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
-    if (a.lane < (unsigned)kRunSlots) *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
+    *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
     __syncthreads();
     return a;
 }
@@ -157,27 +163,29 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     // (bit 0 is always set)
     const unsigned long long m1 = mask >> 1;
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-    if (leader) *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
     const char *rec = reinterpret_cast<const char *>(g.rec);
+    if (npiece > 6u * kRunSlots) {
+        // a fan wider than the slots (rare: > 42 distinct cells across 64 neighbouring rays): every
+        // lane gathers its own record, no cooperation
+        const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)cid * 96u);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = src[k];
+        return;
+    }
+    if (leader) *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
     // passes 0 and 1 (<= 21 runs, the common case): both cell-id reads first, then both DMA loads
     unsigned c0 = read_cell_of_pass<0>(a), c1 = read_cell_of_pass<1>(a);
     asm volatile("" : "+v"(c0), "+v"(c1));                                   // keep the reads ahead of the masks
     dma_pass<0>(rec, a, c0, npiece);
     dma_pass<1>(rec, a, c1, npiece);
-    if (npiece > 128u) {                                                     // wide fans: up to 4 more passes
+    if (npiece > 128u) {                                                     // 22..42 runs: two more passes
         unsigned c2 = read_cell_of_pass<2>(a), c3 = read_cell_of_pass<3>(a);
         asm volatile("" : "+v"(c2), "+v"(c3));
         dma_pass<2>(rec, a, c2, npiece);
         dma_pass<3>(rec, a, c3, npiece);
-        if (npiece > 256u) {
-            unsigned c4 = read_cell_of_pass<4>(a), c5 = read_cell_of_pass<5>(a);
-            asm volatile("" : "+v"(c4), "+v"(c5));
-            dma_pass<4>(rec, a, c4, npiece);
-            dma_pass<5>(rec, a, c5, npiece);
-        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec));
+    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec_v));
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = r[k];
 }
@@ -194,20 +202,28 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
 //          bit-identical to the oracle's "fused" flavour, which spells out the same contractions.
 enum Arith { kExact = 0, kFused = 1 };
 
+// Out-of-grid tracking: a running UNSIGNED maximum of the raw cell indices (a negative index wraps to
+// a huge value), turned into the flag by oob_hit() once per step: one v_max3_u32 per look-up
+// instead of two compares and their mask algebra.
+typedef unsigned OobMax;
+__device__ __forceinline__ int oob_hit(const GridDev &g, OobMax m) { return m > (unsigned)(g.N - 3); }
+
 template <int AR>
-__device__ __forceinline__ int cell_of(double x, const GridDev &g, int &oob)
+__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob, double nb)
 {
     // kExact: floor of the correctly rounded quotient.  kFused: one fma, and the conversion's own
     // truncation stands in for floor (equal for q >= 0; q in (-1,0) lands in cell 0 un-flagged,
     // which the oracle's fused flavour defines the same way).
-    const double q = (AR == kFused) ? __builtin_fma(x, g.rh, g.nb)
+    const double q = (AR == kFused) ? __builtin_fma(x, g.rh, nb)
                                     : __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
     int iraw, i;                                 // v_cvt truncates and saturates; (int)q would be UB out of range
     asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
-    oob |= (i != iraw);
+    oob = (unsigned)iraw > oob ? (unsigned)iraw : oob;
     return i;
 }
+template <int AR>
+__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob) { return cell_of<AR>(x, g, oob, g.nb); }
 
 // H = [c^2 p ; -grad c * c * tau] from one cell record and the in-cell offsets (NonObstacle.jl:37-42),
 // in the chosen arithmetic flavour; also returns c, dc/dx, dc/dy, tau for the Jacobian path.
@@ -243,10 +259,10 @@ __device__ __forceinline__ void h_from_record(const double X[4], double dx, doub
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
 // ALL 64 lanes must be converged here (wave-cooperative record fetch).
 template <int AR>
-__device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], int &oob)
+__device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob)
 {
-    const int i = cell_of<AR>(X[0], g, oob);
-    const int j = cell_of<AR>(X[1], g, oob);
+    const int i = cell_of<AR>(X[0], g, oob, a.nb_v);
+    const int j = cell_of<AR>(X[1], g, oob, a.nb_v);
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
     const double *pt = lds_nodes();
     const double pi_ = pt[i], pj_ = pt[j];
@@ -261,8 +277,10 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
 // per-lane loads (called under divergence, once per ray); as-written arithmetic in both flavours
 __device__ __forceinline__ double speed_grid(const GridDev &g, const double *pt, double x, double y, int &oob)
 {
-    const int i = cell_of<kExact>(x, g, oob);
-    const int j = cell_of<kExact>(y, g, oob);
+    OobMax om = 0;
+    const int i = cell_of<kExact>(x, g, om);
+    const int j = cell_of<kExact>(y, g, om);
+    oob |= oob_hit(g, om);
     const double2 *r = reinterpret_cast<const double2 *>(g.rec) +
                        ((size_t)i + (size_t)j * (size_t)(g.N - 1)) * 6;
     const double2 e01 = r[0], e23 = r[1];
@@ -297,10 +315,19 @@ struct MediumDev {
 };
 
 template <int MED, int AR>
-__device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], int &oob)
+__device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob)
 {
     if (MED == kGrid) rhs_grid<AR>(m.g, pt, X, H, oob);
     else rhs_sinprod(m.sp, X, H);
+}
+
+// fma with a destination of its own (v_fma_f64): the stage update Y = X + H*hdt must leave X alive, and
+// the compiler otherwise picks the two-address v_fmac_f64 plus a 64-bit copy of X per component.
+__device__ __forceinline__ double fma_vop3(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 
 // One classical RK4 step X -> Xn with step dt (dt == 0 leaves Xn == X: how finished lanes idle).
@@ -308,20 +335,20 @@ __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const
 // FORM 1 = a8/a9: k = H;    X + k/2*dt; (k1+2k2+2k3+k4)*dt/6.0    NonObstacle.jl:161-164,171
 // kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)
 template <int MED, int AR, int FORM>
-__device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, int &oob)
+__device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, OobMax &oob)
 {
     double H[4], Y[4], acc[4];
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
         rhs<MED, AR>(m, pt, X, H, oob);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = __builtin_fma(H[k], hdt, X[k]); }
+        for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
         rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = __builtin_fma(H[k], hdt, X[k]); }
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
         rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = __builtin_fma(H[k], dt, X[k]); }
+        for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
         rhs<MED, AR>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);

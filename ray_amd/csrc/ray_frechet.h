@@ -59,8 +59,10 @@ struct PointEval {
 template <int AR>
 __device__ __forceinline__ void point_eval(const GridDev &g, const double X[4], double H[4], PointEval &q, int &oob)
 {
-    q.i = cell_of<AR>(X[0], g, oob);
-    q.j = cell_of<AR>(X[1], g, oob);
+    OobMax om = 0;
+    q.i = cell_of<AR>(X[0], g, om);
+    q.j = cell_of<AR>(X[1], g, om);
+    oob |= oob_hit(g, om);
     const unsigned cid = mad24((unsigned)q.j, (unsigned)(g.N - 1), (unsigned)q.i);
     const double *pt = lds_nodes();
     q.dx = X[0] - pt[q.i];
