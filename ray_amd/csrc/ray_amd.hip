@@ -103,7 +103,7 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 //    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
 //    parked in the output row meanwhile.
 template <int MED, int OB, int AR>
-__global__ __launch_bounds__(256, 5) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused) ? 5 : 1) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
@@ -166,7 +166,12 @@ __global__ __launch_bounds__(256, 5) void k_shoot(const ShootArgs a)
     // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
     if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {   // (live lanes <=> dtl != 0)
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
-        if (active) {
+#ifndef RAY_ABLATE_NOPARK
+        if (active)
+#else
+        if (active && it == 0)
+#endif
+        {
             s_park[threadIdx.x] = make_double2(X[0], X[1]);
             s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
         }
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     }
     double t = 0, dt = a.dt;
     bool active = valid && t < T;
-    while (__any(active)) {
-        if (it >= a.max_steps) break;
+    // one back edge, one exit (wave-uniform); live lanes left at the cap get STEP_CAP below
+    if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {
         double dtl = 0.0;
         if (active) {
             if (a.mode == RAY_TRACE_SHORTEN_CEASE && (t + dt) > T) dt = T - t;    // NonObstacle.jl:153-156
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-    }
+    } while (__builtin_amdgcn_ballot_w64(active) != 0 && it < a.max_steps);
     if (active) st |= kStStepCap;
     if (oob) st |= kStOob;
     if (valid) {

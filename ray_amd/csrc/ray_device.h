@@ -185,6 +185,15 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
         dma_pass<3>(rec, a, c3, npiece);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RAY_ABLATE_NOREAD
+    asm volatile("" :: "v"(rank));
+    out[0] = make_double2(1.0, 0.0);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) out[k] = make_double2(0.0, 0.0);
+    asm volatile("" : "+v"(out[0].x), "+v"(out[0].y), "+v"(out[1].x), "+v"(out[1].y), "+v"(out[2].x), "+v"(out[2].y));
+    asm volatile("" : "+v"(out[3].x), "+v"(out[3].y), "+v"(out[4].x), "+v"(out[4].y), "+v"(out[5].x), "+v"(out[5].y));
+    return;
+#endif
     const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec_v));
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = r[k];
@@ -264,10 +273,18 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
     const int i = cell_of<AR>(X[0], g, oob, a.nb_v);
     const int j = cell_of<AR>(X[1], g, oob, a.nb_v);
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
+#ifdef RAY_ABLATE_PCOMP
+    const double pi_ = __builtin_fma((double)i, g.h, g.p1), pj_ = __builtin_fma((double)j, g.h, g.p1);
+#else
     const double *pt = lds_nodes();
     const double pi_ = pt[i], pj_ = pt[j];
+#endif
     double2 r[6];
+#ifdef RAY_ABLATE_HOT
+    fetch_records(g, a, (cid & 0xff) + 5000, r);     // same run structure, 256-record footprint: always L1-hot
+#else
     fetch_records(g, a, cid, r);
+#endif
     const double dx = X[0] - pi_, dy = X[1] - pj_;
     double c, gcX, gcY, tau;
     h_from_record<AR>(X, dx, dy, r, H, c, gcX, gcY, tau);
