@@ -1354,6 +1354,17 @@ int ray_frechet_fidelity_update(ray_frechet *f, const double *x, const double *m
     return RAY_OK;
 }
 
+#ifdef RAY_STATS
+// instrumentation build only (scripts/): look-up statistics of the cell cache since the last call
+int ray_debug_stats(unsigned long long out[4])
+{
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
+    return RAY_OK;
+}
+#endif
+
 // ---- misfit ---------------------------------------------------------------------------------------
 int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
                    double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev)

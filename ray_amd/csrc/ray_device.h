@@ -51,19 +51,25 @@ __device__ __forceinline__ double div6(double a)
 
 // ---- per-thread access context for the gridded medium -----------------------------------------
 // LDS carve-up per workgroup (dynamic shared memory, see grid_lds_bytes()):
-//   [ p[0..N) node coordinates | per wave: 64 x 96-byte record slots | per wave: 64 cell ids ]
+//   [ p[0..N) node coordinates, padded to 512 B | per wave: 128 cell tags | per wave: 42 x 96-byte
+//     record slots | per wave: 64 cell ids ]
 // The node table leaves the vector-memory path entirely; the record slots are the landing zone of
-// the wave-cooperative record fetch below.
+// the wave-cooperative record fetch below, and the tags make them a small cell cache: a look-up at
+// a nearby position (the next RK4 stage moves a ray by ~1e-4 of a cell) finds its record there
+// without a new fetch.
 constexpr int kRunSlots = 42;                       // record slots per wave; wider fans take the per-lane path
 constexpr int kPasses = 4;                          // global_load_lds passes that fill them (4 x 1 KiB >= 42 x 96 B)
 constexpr int kWaveSlotBytes = kPasses * 1024;
-constexpr int kWaveLdsBytes = kWaveSlotBytes + 64 * 4;
+constexpr int kTagEntries = 128;                    // per wave, 4 bytes each: (cell id << 6) | slot, or kTagEmpty
+constexpr unsigned kTagEmpty = 0xffffffffu;
+constexpr int kWaveLdsBytes = kWaveSlotBytes + 64 * 4 + kTagEntries * 4;
 
 struct GridAcc {
     unsigned wrec;           // LDS byte offset of this wave's record slots
     unsigned wrec_v;         // the same in a VGPR (addend of the per-lane slot address mad)
     double nb_v;             // g.nb in VGPRs: fma(x, rh, nb) may read one SGPR operand only
     unsigned wcells;         // LDS byte offset of this wave's cell-id slots
+    unsigned wtags;          // LDS byte offset of this wave's cell tags (512-byte aligned)
     unsigned lane;
     unsigned role_run4[3];   // loader role slot s (shift 0,4,2): 4 * ((lane + shift) / 6) ...
     unsigned role_poff[3];   // ... and 16 * ((lane + shift) % 6); see fetch_records()
@@ -71,7 +77,7 @@ struct GridAcc {
 
 __host__ __device__ inline size_t grid_lds_bytes(int N, int block)
 {
-    return (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)(block / 64) * kWaveLdsBytes;
+    return (((size_t)N * 8 + 511) & ~(size_t)511) + (size_t)(block / 64) * kWaveLdsBytes;
 }
 
 extern __shared__ __attribute__((aligned(16))) char ray_smem[];   // [ p | record slots | cell ids ]
@@ -83,11 +89,12 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     GridAcc a;
     double *p_lds = reinterpret_cast<double *>(ray_smem);
     for (int k = threadIdx.x; k < g.N; k += blockDim.x) p_lds[k] = g.p[k];
-    const unsigned poff = ((unsigned)g.N * 8u + 15u) & ~15u;
+    const unsigned poff = ((unsigned)g.N * 8u + 511u) & ~511u;
     // wave-uniform by construction; readfirstlane tells the compiler so (LDS bases live in SGPRs)
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    a.wrec = poff + wave * kWaveSlotBytes;
-    a.wcells = poff + nw * kWaveSlotBytes + wave * (64 * 4);
+    a.wtags = poff + wave * (kTagEntries * 4);
+    a.wrec = poff + nw * (kTagEntries * 4) + wave * kWaveSlotBytes;
+    a.wcells = poff + nw * (kTagEntries * 4 + kWaveSlotBytes) + wave * (64 * 4);
     a.lane = threadIdx.x & 63;
     a.wrec_v = a.wrec;
     a.nb_v = g.nb;
@@ -100,6 +107,7 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     }
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
     *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
+    *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
     __syncthreads();
     return a;
 }
@@ -142,7 +150,18 @@ __device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsi
                                          (lptr_t)(ray_smem + a.wrec + T * 1024u), 16, 0, 0);
 }
 
-__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int cid, double2 out[6])
+#ifdef RAY_STATS
+__device__ unsigned long long g_ray_stats[4];   // [0] wave look-ups, [1] with >= 1 miss, [2] missing lanes, [3] wide-fan fetches
+#endif
+
+// Tag slot of cell (i, j): (i + 37 j) mod 128 -- distinct for the cells of one wavefront (a compact arc
+// of at most a few tens of cells); a collision only costs the loser a miss.
+__device__ __forceinline__ unsigned tag_addr(const GridAcc &a, int i, int j)
+{
+    return ((mad24((unsigned)j, 37u * 4u, (unsigned)i << 2)) & (unsigned)(kTagEntries * 4 - 4)) | a.wtags;
+}
+
+__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6])
 {
 #ifdef RAY_ABLATE_NOFETCH
     asm volatile("" :: "v"(cid));
@@ -164,15 +183,24 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     const unsigned long long m1 = mask >> 1;
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
     const char *rec = reinterpret_cast<const char *>(g.rec);
+    // the slots are about to be overwritten: forget what the tags said about them
+    *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
     if (npiece > 6u * kRunSlots) {
-        // a fan wider than the slots (rare: > 42 distinct cells across 64 neighbouring rays): every
-        // lane gathers its own record, no cooperation
+#ifdef RAY_STATS
+        if (a.lane == 0) atomicAdd(&g_ray_stats[3], 1ull);
+#endif
+        // a fan wider than the slots (> 42 distinct cells across 64 neighbouring rays, ~10 % of the
+        // fetches of the 2048^2 sweep): every lane gathers its own record, no cooperation.  (Serving
+        // the first 42 runs from the slots was tried: the extra live values cost more than it saves.)
         const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)cid * 96u);
 #pragma unroll
         for (int k = 0; k < 6; ++k) out[k] = src[k];
         return;
     }
-    if (leader) *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
+    if (leader) {
+        *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
+        *reinterpret_cast<unsigned *>(ray_smem + tag_addr(a, i, j)) = ((unsigned)cid << 6) | rank;
+    }
     // passes 0 and 1 (<= 21 runs, the common case): both cell-id reads first, then both DMA loads
     unsigned c0 = read_cell_of_pass<0>(a), c1 = read_cell_of_pass<1>(a);
     asm volatile("" : "+v"(c0), "+v"(c1));                                   // keep the reads ahead of the masks
@@ -197,6 +225,39 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec_v));
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = r[k];
+}
+
+// Look-up through the tags (ALL 64 lanes together): the record of cell `cid` if the last
+// fetch_records() of this wave brought it in -- for this lane or for any other -- else this lane
+// gathers it from memory itself.  Same bytes either way: the path taken never shows in the results.
+__device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6])
+{
+#if defined(RAY_ABLATE_NOFETCH) || defined(RAY_ABLATE_NOCACHE)
+    fetch_records(g, a, i, j, cid, out);
+    return;
+#endif
+    const unsigned tag = *reinterpret_cast<const unsigned *>(ray_smem + tag_addr(a, i, j));
+    const bool hit = (tag >> 6) == (unsigned)cid;
+    const unsigned slot = hit ? (tag & 63u) : 0u;
+    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(slot, 96u, a.wrec_v));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[k] = r[k];
+#ifdef RAY_STATS
+    {
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(!hit);
+        if (a.lane == 0) {
+            atomicAdd(&g_ray_stats[0], 1ull);
+            if (mm) { atomicAdd(&g_ray_stats[1], 1ull); atomicAdd(&g_ray_stats[2], (unsigned long long)__popcll(mm)); }
+        }
+    }
+#endif
+    if (__builtin_amdgcn_ballot_w64(!hit) != 0) {
+        if (!hit) {
+            const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(g.rec) + (size_t)cid * 96u);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = src[k];
+        }
+    }
 }
 
 // ---- arithmetic flavours of the gridded right-hand side and RK4 combination -----------------
@@ -267,7 +328,12 @@ __device__ __forceinline__ void h_from_record(const double X[4], double dx, doub
 
 // a2 / a3(H): DiscreteHamilton                                     NonObstacle.jl:30-42
 // ALL 64 lanes must be converged here (wave-cooperative record fetch).
-template <int AR>
+// FETCH: wave-cooperative fetch of this position's cells (and tags for them); LOOKUP: served from the
+// cells of the previous FETCH where possible.  RK4 stage positions pair up -- stage 3 sits ~dt^2 from
+// stage 2, the next step's stage 1 ~dt^2 from stage 4 -- so stages 2 and 4 FETCH, stages 3 and 1 LOOKUP.
+enum RecMode { kFetch = 0, kLookup = 1 };
+
+template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob)
 {
     const int i = cell_of<AR>(X[0], g, oob, a.nb_v);
@@ -281,9 +347,10 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
 #endif
     double2 r[6];
 #ifdef RAY_ABLATE_HOT
-    fetch_records(g, a, (cid & 0xff) + 5000, r);     // same run structure, 256-record footprint: always L1-hot
+    fetch_records(g, a, i, j, (cid & 0xff) + 5000, r);     // same run structure, 256-record footprint: always L1-hot
 #else
-    fetch_records(g, a, cid, r);
+    if (MODE == kLookup) lookup_records(g, a, i, j, cid, r);
+    else fetch_records(g, a, i, j, cid, r);
 #endif
     const double dx = X[0] - pi_, dy = X[1] - pj_;
     double c, gcX, gcY, tau;
@@ -331,10 +398,10 @@ struct MediumDev {
     SinProdDev sp;
 };
 
-template <int MED, int AR>
+template <int MED, int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob)
 {
-    if (MED == kGrid) rhs_grid<AR>(m.g, pt, X, H, oob);
+    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob);
     else rhs_sinprod(m.sp, X, H);
 }
 
@@ -357,43 +424,43 @@ __device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const
     double H[4], Y[4], acc[4];
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }
