@@ -67,7 +67,8 @@ struct ShootArgs {
     int init;
     int nd;
     int nsrc;               // sources in this call (src_end - src_begin)
-    int ngroup;             // source groups per direction chunk = ceil(nsrc / waves per block)
+    int ngroup;             // source groups per direction chunk = ceil(nsrc / (waves per block * sources per wave))
+    int dshift;             // log2 of the directions per wave: a wave is 2^(6-dshift) sources x 2^dshift directions
     const double *src;      // source[i]            (local index i - src_begin)
     const double *src_cos;  // cos(source[i])  host libm
     const double *src_sin;  // sin(source[i])
@@ -118,14 +119,16 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     int64_t il = 0;
     int j = 0;
     if (a.init) {
-        const int nchunk = (a.nd + 63) >> 6;
+        const int dmask = (1 << a.dshift) - 1;
+        const int nchunk = (a.nd + dmask) >> a.dshift;
         const int rank = (int)(blockIdx.x / (unsigned)a.ngroup);
         int gi = (int)(blockIdx.x - (unsigned)rank * (unsigned)a.ngroup);
         if ((a.ngroup & 7) == 0) gi = (gi & 7) * (a.ngroup >> 3) + (gi >> 3);
         const int mid = nchunk >> 1, hh = (rank + 1) >> 1;
         const int chunk = (rank & 1) ? mid - hh : mid + hh;
-        il = (int64_t)gi * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        j = chunk * 64 + (int)(threadIdx.x & 63);
+        const int lane = (int)(threadIdx.x & 63);
+        il = (((int64_t)gi * (blockDim.x >> 6) + (threadIdx.x >> 6)) << (6 - a.dshift)) + (lane >> a.dshift);
+        j = (chunk << a.dshift) + (lane & dmask);
         valid = il < a.nsrc && j < a.nd;
         r = il * a.nd + j;
     } else {
@@ -785,8 +788,17 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     const int bt = block_threads(), wpb = bt / 64;
     unsigned nblk;
     if (a.init) {
-        a.ngroup = (a.nsrc + wpb - 1) / wpb;
-        nblk = (unsigned)(((a.nd + 63) / 64) * a.ngroup);
+        // wave shape: 64 directions of one source by default; RAY_WAVE_DIRS=32/16/8 makes a wave a patch of
+        // 2/4/8 adjacent sources x that many directions (narrower fans: fewer distinct cells per wave)
+        static const int dshift = [] {
+            const char *e = getenv("RAY_WAVE_DIRS");
+            const int v = e ? atoi(e) : 64;
+            return v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 6;
+        }();
+        a.dshift = dshift;
+        const int spb = wpb << (6 - dshift), dpw = 1 << dshift;      // sources per block, directions per wave
+        a.ngroup = (a.nsrc + spb - 1) / spb;
+        nblk = (unsigned)(((a.nd + dpw - 1) / dpw) * a.ngroup);
     } else nblk = (unsigned)((a.num + bt - 1) / bt);
     const dim3 grid(nblk), block(bt);
     const size_t lds = nodes_lds_bytes(med);
