@@ -201,6 +201,20 @@ int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const d
                                     const uint8_t *ray_mask_dev, double rejection, double decay,
                                     double *fidelity_dev, double *residual_dev);
 
+/* ---- ray classification (Utility.jl:1-39; ObstacleDemo.jl:48-67; SURVEY.md section 8f NEXT-3) -----------
+ * m: (ns*nd, >=8 columns), rows source-major as ScatterRelation(Obstacle) writes them.
+ *   ortho[r] = similarity(m[r,1:2], m[r,5:6]) > 0.995 && similarity(m[r,3:4], m[r,7:8]) < -0.995
+ *              (the `orthoIndex` filter, ObstacleDemo.jl:48-49; may be NULL)
+ *   arg      = alignment(atan2.(m[.,6], m[.,5])) per source (Utility.jl:5-13; ObstacleDemo.jl:59-61);
+ *              num doubles, workspace and output (host form: may be NULL)
+ *   lo, hi   = derivativeCheck(arg) per source, 1-BASED like the reference (Utility.jl:15-39): the
+ *              unbroken rays of source s are rows 1..lo and hi..nd of its block (ObstacleDemo.jl:63-64).
+ * atan2 / cos are the device library's (<= 2 ulp from the host's): thresholds are compared on those. */
+int ray_classify(ray_ctx *ctx, const double *m_host, int64_t ns, int64_t nd, int64_t ld, uint8_t *ortho,
+                 double *arg, int32_t *lo, int32_t *hi);
+int ray_classify_dev(ray_ctx *ctx, const double *m_dev, int64_t ns, int64_t nd, int64_t ld,
+                     uint8_t *ortho_dev, double *arg_dev, int32_t *lo_dev, int32_t *hi_dev);
+
 /* ---- misfit (NonObstacle.jl:287,336,372; ObstacleDemo.jl:202,219-226,252) ------------------
  * out[0] = sum_r,k (m[r,4+k]-obs[r,4+k])^2, out[1] = sum_r,k m[r,4+k]^2  (objective =
  * sqrt(out[0]/out[1])); mask[r] = |m[r,5:8]-obs[r,5:8]| / |m[r,5:8]| < perc_thresh;

@@ -237,3 +237,52 @@ def loop_fidelity(M, correction, mismatch, rows, fidelity, rejection, decay):
             ids = M.indices[M.indptr[row]:M.indptr[row + 1]]
             fid[ids] = np.maximum(fid[ids], 1 - decay * residual[k])
     return fid, residual
+
+
+# ---- NEXT-3: ray classification (Utility.jl:1-39; ObstacleDemo.jl:48-67), pure-Python restatement -------
+def similarity(X, Y):                                            # Utility.jl:1-3
+    import math
+    return math.cos(math.atan2(X[0], X[1]) - math.atan2(Y[0], Y[1]))
+
+
+def alignment(signal):                                           # Utility.jl:5-13 (in place on a list)
+    import math
+    n = len(signal)
+    for i in range(1, n):
+        d = signal[i] - signal[i - 1]
+        if abs(d) > 1.5 * math.pi:
+            sh = (1.0 if d > 0 else -1.0 if d < 0 else 0.0) * 2 * math.pi
+            for k in range(i, n):
+                signal[k] = signal[k] - sh
+    return signal
+
+
+def derivative_check(signal):                                    # Utility.jl:15-39, 1-based lo / hi
+    n = len(signal)
+    deriv = [signal[i + 1] - signal[i] for i in range(n - 1)]    # deriv[i-1] = Julia deriv[i]
+    lo, hi = 1, n
+    for i in range(1, n - 1):
+        if abs(deriv[i - 1] - deriv[i]) > 0.12:
+            lo = i
+            break
+    for i in range(n - 1, 1, -1):
+        if abs(deriv[i - 1] - deriv[i - 2]) > 0.12:
+            hi = i + 1
+            break
+    if abs(lo - hi) < n / 8:
+        lo, hi = 1, n
+    return lo, hi
+
+
+def classify(m, ns, nd):
+    """ObstacleDemo.jl:48-67: (ortho index list 0-based, lo[ns], hi[ns] 1-based, aligned arg (ns, nd))."""
+    import math
+    ortho = [r for r in range(ns * nd)
+             if similarity(m[r, 0:2], m[r, 4:6]) > 0.995 and similarity(m[r, 2:4], m[r, 6:8]) < -0.995]
+    lo, hi, args = [], [], []
+    for s in range(ns):
+        arg = [math.atan2(m[s * nd + j, 5], m[s * nd + j, 4]) for j in range(nd)]
+        arg = alignment(arg)
+        l, h = derivative_check(arg)
+        lo.append(l); hi.append(h); args.append(arg)
+    return np.array(ortho, dtype=np.int64), np.array(lo), np.array(hi), np.array(args)

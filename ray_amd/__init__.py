@@ -394,6 +394,30 @@ def NonReflectionTrace(c, m, ext, dt, *, ctx=None, info=False):
     return (out, inf) if info else out
 
 
+def classify_rays(m, ns, nd, *, ctx=None):
+    """Utility.jl:1-39 + ObstacleDemo.jl:48-67 on the GPU.  Returns a dict with 0-based numpy index
+    arrays `ortho_index` (:48-49), `unbroken` (:63-64), `unbroken_bound` (:65-66), the per-source 1-based
+    `lo`, `hi` of derivativeCheck and the aligned exit angles `arg` (ns, nd)."""
+    ctx = ctx or default_context()
+    m = np.asfortranarray(m, dtype=np.float64)
+    num = ns * nd
+    if m.shape[0] != num or m.shape[1] < 8:
+        raise ValueError("m must be (ns*nd, >= 8)")
+    ortho = np.zeros(num, dtype=np.uint8)
+    arg = np.zeros(num, dtype=np.float64)
+    lo = np.zeros(ns, dtype=np.int32)
+    hi = np.zeros(ns, dtype=np.int32)
+    _lib.check(ctx._lib.ray_classify(ctx.handle, _ptr(m), ns, nd, max(num, 1), _ptr(ortho), _ptr(arg), _ptr(lo), _ptr(hi)))
+    unbroken, bound = [], []
+    for s in range(ns):                                    # ObstacleDemo.jl:63-66 (1-based -> 0-based rows)
+        unbroken.append(np.arange(s * nd, s * nd + lo[s]))
+        unbroken.append(np.arange(s * nd + hi[s] - 1, (s + 1) * nd))
+        bound += [s * nd + lo[s] - 1, s * nd + hi[s] - 1]
+    return {"ortho_index": np.flatnonzero(ortho), "lo": lo, "hi": hi, "arg": arg.reshape(ns, nd),
+            "unbroken": np.concatenate(unbroken) if unbroken else np.zeros(0, dtype=np.int64),
+            "unbroken_bound": np.array(bound, dtype=np.int64)}
+
+
 def misfit(m, obs, perc_thresh=0.2, *, ctx=None):
     """NonObstacle.jl:336,372; ObstacleDemo.jl:219-226.  Returns dict with `mismatch` (4*num,
     ray-major), `sum_mismatch2`, `sum_target2`, `objective`, `mask` (perc < perc_thresh)."""

@@ -333,6 +333,65 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     if ((threadIdx.x & 63) == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
 }
 
+// ---- NEXT-3: ray classification (Utility.jl:1-39; ObstacleDemo.jl:48-67) ------------------------------
+// similarity(X, Y) = cos(atan2(X[1], X[2]) - atan2(Y[1], Y[2]))                      Utility.jl:1-3
+__device__ __forceinline__ double similarity(double x1, double x2, double y1, double y2)
+{
+    return cos(atan2(x1, x2) - atan2(y1, y2));
+}
+
+// orthoIndex filter (ObstacleDemo.jl:48-49) per ray, and arg = atan2(m[:,6], m[:,5]) (:59-60)
+__global__ __launch_bounds__(256) void k_classify_rays(const double *__restrict__ m, int64_t num, int64_t ld,
+                                                       uint8_t *__restrict__ ortho, double *__restrict__ arg)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num) return;
+    const double x0 = m[r], y0 = m[r + ld], p0 = m[r + 2 * ld], q0 = m[r + 3 * ld];
+    const double x1 = m[r + 4 * ld], y1 = m[r + 5 * ld], p1 = m[r + 6 * ld], q1 = m[r + 7 * ld];
+    if (ortho) ortho[r] = (similarity(x0, y0, x1, y1) > 0.995 && similarity(p0, q0, p1, q1) < -0.995) ? 1 : 0;
+    arg[r] = atan2(y1, x1);
+}
+
+// alignment + derivativeCheck (Utility.jl:5-39) of one source's exit-angle signal, in place; one thread
+// per source, sequential like the reference (every later value depends on the earlier corrections)
+__global__ __launch_bounds__(64) void k_unbroken(double *__restrict__ arg, int64_t ns, int64_t nd,
+                                                 int32_t *__restrict__ lo_out, int32_t *__restrict__ hi_out)
+{
+    const int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= ns) return;
+    double *sig = arg + sidx * nd;
+    const int64_t n = nd;
+    const double two_pi = 2 * 3.141592653589793, lim = 1.5 * 3.141592653589793;
+    // signal[i:n] -= sign(jump) * 2pi at every jump: a running shift applied as the scan passes; the jump
+    // test sees both neighbours shifted by the same corrections, exactly as in the in-place original
+    double prev = n > 0 ? sig[0] : 0.0;
+    for (int64_t i = 1; i < n; ++i) {
+        // values right of i carry all corrections made so far: apply them one by one, in order
+        double v = sig[i];
+        sig[i] = v;
+        const double d = v - prev;
+        if (__builtin_fabs(d) > lim) {
+            const double sh = (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0)) * two_pi;
+            for (int64_t k = i; k < n; ++k) sig[k] = sig[k] - sh;
+            v = sig[i];
+        }
+        prev = v;
+    }
+    int64_t lo = 1, hi = n;
+    for (int64_t i = 1; i <= n - 2; ++i) {                       // deriv[i] = signal[i+1] - signal[i], 1-based
+        const double d0 = sig[i] - sig[i - 1], d1 = sig[i + 1] - sig[i];
+        if (__builtin_fabs(d0 - d1) > 0.12) { lo = i; break; }
+    }
+    for (int64_t i = n - 1; i >= 2; --i) {
+        const double d0 = sig[i] - sig[i - 1], dm = sig[i - 1] - sig[i - 2];
+        if (__builtin_fabs(d0 - dm) > 0.12) { hi = i + 1; break; }
+    }
+    const int64_t gap = lo > hi ? lo - hi : hi - lo;
+    if ((double)gap < (double)n / 8) { lo = 1; hi = n; }
+    lo_out[sidx] = (int32_t)lo;
+    hi_out[sidx] = (int32_t)hi;
+}
+
 // a11: misfit sums, per-ray selection mask, ray-major mismatch vector.
 // Stage 1: fixed grid of kMisfitBlocks x 256 threads, grid-stride over rays, LDS tree per block.
 // Stage 2: one block folds the kMisfitBlocks partials.  Order is fixed -> reproducible.
@@ -1363,6 +1422,46 @@ int ray_frechet_fidelity_update(ray_frechet *f, const double *x, const double *m
     if ((rc = fi.down(f->ctx, fidelity, n2 * 8))) return rc;
     if (residual && (rc = res.down(f->ctx, residual, (size_t)f->num * 32))) return rc;
     HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+// ---- NEXT-3: ray classification ----------------------------------------------------------------------
+int ray_classify_dev(ray_ctx *ctx, const double *m_dev, int64_t ns, int64_t nd, int64_t ld, uint8_t *ortho_dev,
+                     double *arg_dev, int32_t *lo_dev, int32_t *hi_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    const int64_t num = ns * nd;
+    if (!m_dev || !arg_dev || !lo_dev || !hi_dev || ns < 0 || nd < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad classify arguments");
+    if (num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_classify_rays, dim3((unsigned)((num + 255) / 256)), dim3(256), 0, ctx->stream, m_dev, num, ld,
+                       ortho_dev, arg_dev);
+    hipLaunchKernelGGL(k_unbroken, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, arg_dev, ns, nd, lo_dev, hi_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_classify(ray_ctx *ctx, const double *m_host, int64_t ns, int64_t nd, int64_t ld, uint8_t *ortho,
+                 double *arg, int32_t *lo, int32_t *hi)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    const int64_t num = ns * nd;
+    if (!m_host || !lo || !hi || ns < 0 || nd < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad classify arguments");
+    if (num == 0) return RAY_OK;
+    DevBuf dm, dor, darg, dlo, dhi;
+    HIPCHK(dm.alloc(sizeof(double) * 8 * (size_t)num));
+    HIPCHK(dor.alloc((size_t)num));
+    HIPCHK(darg.alloc(sizeof(double) * (size_t)num));
+    HIPCHK(dlo.alloc(sizeof(int32_t) * (size_t)ns));
+    HIPCHK(dhi.alloc(sizeof(int32_t) * (size_t)ns));
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 8))) return rc;
+    if ((rc = ray_classify_dev(ctx, dm.as<double>(), ns, nd, num, dor.as<uint8_t>(), darg.as<double>(), dlo.as<int32_t>(), dhi.as<int32_t>()))) return rc;
+    if (ortho) HIPCHK(hipMemcpyAsync(ortho, dor.p, (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+    if (arg) HIPCHK(hipMemcpyAsync(arg, darg.p, sizeof(double) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(lo, dlo.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hi, dhi.p, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;
 }
 
