@@ -201,6 +201,16 @@ int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const d
                                     const uint8_t *ray_mask_dev, double rejection, double decay,
                                     double *fidelity_dev, double *residual_dev);
 
+/* ---- ray paths (ScatterRelationObstaclePlot, Obstacle.jl:98-221, without the plotting; SURVEY.md 8f
+ * NEXT-4).  As ray_shoot_states, and additionally the polyline `res` of every ray: its start, the
+ * position after every step, each reflection point (twice, as the reference appends R and then the
+ * reflected X), the exit point (Obstacle.jl:114,142,175,211).  path_host: [ray][point][x,y], max_pts
+ * points per ray; npts[ray] = points the ray produced (> max_pts: the tail was dropped).             */
+int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt,
+                    int32_t time_unit, int32_t max_steps, double *m_host, int64_t num, int64_t ld,
+                    int32_t max_pts, double *path_host, int32_t *npts, int32_t *status,
+                    int32_t *nsteps, int32_t *nreflect);
+
 /* ---- ray classification (Utility.jl:1-39; ObstacleDemo.jl:48-67; SURVEY.md section 8f NEXT-3) -----------
  * m: (ns*nd, >=8 columns), rows source-major as ScatterRelation(Obstacle) writes them.
  *   ortho[r] = similarity(m[r,1:2], m[r,5:6]) > 0.995 && similarity(m[r,3:4], m[r,7:8]) < -0.995

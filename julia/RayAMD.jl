@@ -24,7 +24,7 @@ using SharedArrays   # NonObstacleReconstruction requires m::SharedArray{Float64
 
 export SinProd, Circle, smooth_demo, obstacle_demo,
        ScatterRelation, ScatterRelationObstacle, ScatterForwardOperator, NonReflectionTrace,
-       misfit, set_arith!, ARITH_EXACT, ARITH_FUSED
+       misfit, set_arith!, ARITH_EXACT, ARITH_FUSED, read_rayfix
 
 const LIB = get(ENV, "RAY_AMD_LIB", joinpath(@__DIR__, "..", "ray_amd", "libray_amd.so"))
 
@@ -198,6 +198,27 @@ function misfit(m::AbstractMatrix{Float64}, observation::AbstractMatrix{Float64}
                 (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Int64, Ptr{Cdouble}, Ptr{UInt8}, Cdouble, Ptr{Cdouble}),
                 context(), a, b, num, max(num, 1), out, mask, perc_thresh, mism))
     mism, sqrt(out[1] / out[2]), mask
+end
+
+# ---- RAYFIX1 reader (ray_amd/fixture.py): the golden vectors of tests/golden for a Julia-side check -----
+# scripts/npz_to_rayfix.py writes them; arrays come back column-major, exactly as stored.
+function read_rayfix(path::AbstractString)
+    open(path, "r") do io
+        readline(io) == "RAYFIX1" || error("$path: not a RAYFIX1 file")
+        head = readline(io)
+        body = read(io)
+        out = Dict{String,Any}()
+        # minimal parse of {"arrays": [{"name": "..", "dtype": "..", "shape": [..], "offset": n}, ...]}
+        for mt in eachmatch(r"\{\"name\": \"([^\"]+)\", \"dtype\": \"(\w+)\", \"shape\": \[([^\]]*)\], \"offset\": (\d+)\}", head)
+            T = Dict("f8" => Float64, "i4" => Int32, "i8" => Int64, "u1" => UInt8)[mt.captures[2]]
+            shape = isempty(strip(mt.captures[3])) ? () : Tuple(parse.(Int, split(mt.captures[3], ",")))
+            off = parse(Int, mt.captures[4])
+            n = prod(shape)                                   # prod(()) == 1: a scalar
+            v = collect(reinterpret(T, body[off + 1:off + n * sizeof(T)]))
+            out[mt.captures[1]] = isempty(shape) ? v[1] : reshape(v, shape)
+        end
+        out
+    end
 end
 
 end # module

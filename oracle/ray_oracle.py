@@ -164,12 +164,15 @@ def _rk4_kdt(med, X, dt):  # NonObstacle.jl:72-76
     return [X[k] + (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) / 6.0 for k in range(4)], oob
 
 
-def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000):
+def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000, paths=None):
     """a6 (NonObstacle.jl:67-97) / a7 (Obstacle.jl:23-95).  rows: list of [x,y,px,py].
-    Returns list of (X1[4], t, status, nsteps, nreflect)."""
+    Returns list of (X1[4], t, status, nsteps, nreflect).  paths (a list) receives, per ray, the
+    polyline `res` of the *Plot tracers (Obstacle.jl:114,142,175,211): start, every step's position,
+    reflection points, the exit point."""
     out = []
     for X0 in rows:
         X = list(X0)
+        res = [(X[0], X[1])]
         t = 0
         rfl = st = steps = nref = 0
         while True:
@@ -202,6 +205,7 @@ def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000):
                     E = [(1 - mid) * prev[k] + mid * X[k] for k in range(4)]
                     e = sqrt(E[0] * E[0] + E[1] * E[1]) - 1
                 t = t - (1 - mid) if time_unit else t - (1 - mid) * dt
+                res.append((E[0], E[1]))
                 X = E
                 st |= ST_EXITED
                 break
@@ -223,12 +227,16 @@ def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000):
                     mid = (lo + hi) / 2
                     R = [(1 - mid) * prev[k] + mid * X[k] for k in range(4)]
                     e = obstacle.ob(R[0], R[1])
+                res.append((R[0], R[1]))
                 n = obstacle.normal(R[0], R[1])
                 tn = [2 * n[0], 2 * n[1]]
                 M = [[1 - tn[0] * n[0], 0 - tn[0] * n[1]], [0 - tn[1] * n[0], 1 - tn[1] * n[1]]]
                 X = [R[0], R[1], M[0][0] * R[2] + M[0][1] * R[3], M[1][0] * R[2] + M[1][1] * R[3]]
                 nref += 1
+            res.append((X[0], X[1]))
         out.append((X, float(t), st, steps, nref))
+        if paths is not None:
+            paths.append(res)
     return out
 
 

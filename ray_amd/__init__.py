@@ -254,6 +254,43 @@ def shoot_states(c, m, dt, ob=None, time_unit=TIME_SECONDS, *, ctx=None, max_ste
     return {"status": st, "nsteps": nst, "nreflect": nrf}
 
 
+def shoot_paths(c, m, dt, ob=None, time_unit=TIME_SECONDS, *, ctx=None, max_steps=0, max_pts=4096):
+    """What ScatterRelationObstaclePlot collects before it plots (Obstacle.jl:98-221): shoots the rays
+    of m[:,1:4] (in place, like shoot_states) and returns (paths, info): paths[k] is the (npts, 2)
+    polyline of ray k -- start, every step, reflection points, exit point."""
+    ctx = ctx or default_context()
+    med = _resolve(c, None, ctx)
+    if not (m.flags.f_contiguous and m.dtype == np.float64 and m.ndim == 2 and m.shape[1] == 9):
+        raise ValueError("m must be float64 Fortran-ordered (num, 9)")
+    num = m.shape[0]
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    nrf = np.zeros(num, dtype=np.int32)
+    npts = np.zeros(num, dtype=np.int32)
+    path = np.zeros((num, max_pts, 2), dtype=np.float64)
+    obs = ob._struct() if ob is not None else None
+    _lib.check(ctx._lib.ray_shoot_paths(ctx.handle, med.handle, C.byref(obs) if obs else None, float(dt),
+                                        time_unit, max_steps, _ptr(m), num, max(num, 1), max_pts,
+                                        _ptr(path), _ptr(npts), _ptr(st), _ptr(nst), _ptr(nrf)))
+    if num and npts.max() > max_pts:
+        raise RayError(f"a ray produced {int(npts.max())} points; raise max_pts (= {max_pts})")
+    return [path[k, :npts[k]].copy() for k in range(num)], {"status": st, "nsteps": nst, "nreflect": nrf, "npts": npts}
+
+
+def ScatterRelationObstaclePlot(c, gradc, ob, gradob, ns, nd, dt, rayIndex, *, ctx=None):
+    """Obstacle.jl:98-221 without PyPlot: returns (m, paths) -- m as the reference fills it (rows of
+    rayIndex [0-based here] shot, the others carrying their initial state only) and the polylines of
+    the selected rays, ready for `plot(p[:,0], p[:,1])`."""
+    ctx = ctx or default_context()
+    m = ScatterRelationObstacle(c, gradc, ob, gradob, ns, nd, dt, ctx=ctx)
+    m[:, 4:] = 0.0
+    idx = np.asarray(rayIndex, dtype=np.int64)
+    sel = np.asfortranarray(m[idx])
+    paths, _ = shoot_paths(c, sel, dt, ob, TIME_STEPS, ctx=ctx)
+    m[idx] = sel
+    return m, paths
+
+
 def _trace(c, m, ext, dt, mode, ctx, info):
     ctx = ctx or default_context()
     if isinstance(c, SinProd):

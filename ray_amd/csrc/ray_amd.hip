@@ -81,6 +81,11 @@ struct ShootArgs {
     int64_t num, ld;
     int32_t *status, *nsteps, *nreflect;
     unsigned long long *step_counter;
+    // PATH kernels only: the polyline of every ray ([ray][point][x,y], at most max_pts points kept) as the
+    // reference's *Plot tracers collect it (Obstacle.jl:114,142,175,211)
+    double *path;
+    int32_t *npts;
+    int max_pts;
 };
 
 __device__ __forceinline__ double ob_val(double r0, double x, double y) { return norm2(x, y) - r0; }
@@ -103,8 +108,8 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 //  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
 //    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
 //    parked in the output row meanwhile.
-template <int MED, int OB, int AR>
-__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused) ? 5 : 1) void k_shoot(const ShootArgs a)
+template <int MED, int OB, int AR, int PATH = 0>
+__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? 5 : 1) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
@@ -156,6 +161,15 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         }
         if (!(X[0] == X[0]) || !(X[1] == X[1])) oob = 1;    // NaN position: see cell_of()
     }
+    int np = 0;                                             // PATH: points recorded so far
+    auto put = [&](double x, double y) {
+        if (np < a.max_pts) {
+            double2 *dst = reinterpret_cast<double2 *>(a.path) + (r * a.max_pts + np);
+            *dst = make_double2(x, y);
+        }
+        ++np;
+    };
+    if (PATH && valid) put(X[0], X[1]);                     // res = X[1:2]           Obstacle.jl:114
     // pre-step state (NonObstacle.jl:71 `prev`) of every live lane, parked in LDS each step so that
     // the step can update X in place; a lane stops writing when it exits, which leaves its pre-exit
     // state there for the deferred bisection
@@ -216,8 +230,10 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
                     Xn[2] = m11 * E[2] + m12 * E[3];
                     Xn[3] = m21 * E[2] + m22 * E[3];
                     ++nref;
+                    if (PATH) put(E[0], E[1]);              // res = [res R[1:2]]      Obstacle.jl:175
                 }
             }
+            if (PATH && active) put(Xn[0], Xn[1]);          // res = [res X[1:2]]      Obstacle.jl:211
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
@@ -242,6 +258,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         t = a.time_unit ? t - (1 - mid) : t - (1 - mid) * dt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = E[k];
+        if (PATH) put(E[0], E[1]);                          // res = [res E[1:2]]      Obstacle.jl:142
     }
     if (oob) st |= kStOob;
     if (valid) {
@@ -251,6 +268,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         if (a.status) a.status[r] = st;
         if (a.nsteps) a.nsteps[r] = steps;
         if (a.nreflect) a.nreflect[r] = nref;
+        if (PATH && a.npts) a.npts[r] = np;
     }
     const unsigned wsum = wave_sum((unsigned)steps);
     if ((threadIdx.x & 63) == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
@@ -865,7 +883,20 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
     const bool fused = ctx->arith == RAY_ARITH_FUSED;
-    if (med->kind == kGrid) {
+    if (a.path) {
+        if (med->kind == kGrid) {
+            if (obk == RAY_OB_NONE) {
+                if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kFused, 1>), grid, block, lds, ctx->stream, a);
+                else hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kExact, 1>), grid, block, lds, ctx->stream, a);
+            } else {
+                if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kFused, 1>), grid, block, lds, ctx->stream, a);
+                else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kExact, 1>), grid, block, lds, ctx->stream, a);
+            }
+        } else {
+            if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone, kExact, 1>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle, kExact, 1>), grid, block, 0, ctx->stream, a);
+        }
+    } else if (med->kind == kGrid) {
         if (obk == RAY_OB_NONE) {
             if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kFused>), grid, block, lds, ctx->stream, a);
             else hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kExact>), grid, block, lds, ctx->stream, a);
@@ -1020,6 +1051,43 @@ int ray_shoot_states(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob
                               ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, 4, 5))) return rc;
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// ---- ray paths (NEXT-4: what the reference's *Plot tracers collect, Obstacle.jl:98-221) ------------------
+int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, double dt, int32_t time_unit,
+                    int32_t max_steps, double *m_host, int64_t num, int64_t ld, int32_t max_pts,
+                    double *path_host, int32_t *npts, int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if ((rc = check_med(ctx, med))) return rc;
+    if (!m_host || !path_host || !npts || num < 0 || ld < num || max_pts < 1) return fail(RAY_ERR_INVALID, "bad m / path / npts / num / ld / max_pts");
+    if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
+    if (time_unit != RAY_TIME_SECONDS && time_unit != RAY_TIME_STEPS) return fail(RAY_ERR_INVALID, "bad time_unit");
+    if (num == 0) return RAY_OK;
+    const size_t pbytes = sizeof(double) * 2 * (size_t)max_pts * (size_t)num;
+    DevBuf dm, dpath, dnp;
+    RayOutBufs ob_;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dpath.alloc(pbytes));
+    HIPCHK(dnp.alloc(sizeof(int32_t) * (size_t)num));
+    if ((rc = ob_.alloc(num))) return rc;
+    HIPCHK(hipMemsetAsync(dpath.p, 0, pbytes, ctx->stream));
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
+    ShootArgs a{};
+    a.init = 0; a.nd = 1;
+    a.dt = dt; a.time_unit = time_unit; a.max_steps = max_steps;
+    a.m = dm.as<double>(); a.num = num; a.ld = num;
+    a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>(); a.nreflect = ob_.nr.as<int32_t>();
+    a.path = dpath.as<double>(); a.npts = dnp.as<int32_t>(); a.max_pts = max_pts;
+    rc = launch_shoot(ctx, med, ob, a);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, 4, 5))) return rc;
+    HIPCHK(hipMemcpyAsync(path_host, dpath.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(npts, dnp.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;
