@@ -73,3 +73,64 @@ def test_two_rank_sweep_matches_single_process():
     for r in res:                                           # every rank holds the global sums
         assert abs(r[5][0] - out[0]) <= 1e-12 * out[0] and abs(r[5][1] - out[1]) <= 1e-12 * out[1]
         assert abs(r[6] - np.sqrt(out[0] / out[1])) <= 1e-12
+
+
+def _worker_loop(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scipy.sparse as sps
+    import torch
+    import torch.distributed as dist
+    import orc
+    from ray_amd.dist import theta_block, allreduce_loop_sums, allreduce_fidelity
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ns, nd, N = 7, 12, 21
+    b0, e0 = theta_block(ns, rank, world)
+    m = np.asfortranarray(orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, src_begin=b0, src_end=e0)[0])
+    c0 = np.asfortranarray(1.0 + 0.5 * (orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) - 1.0))
+    X, rho, M, st, _ = orc.forward_operator(orc.GridTables(c0, 1.5), m, 5e-2)
+    mism = (m[:, 4:8] - X).reshape(-1)
+    sums = torch.tensor([float(mism @ mism), float((m[:, 4:8] ** 2).sum())], dtype=torch.float64)
+    b = torch.from_numpy(M.T @ mism)                       # this rank's rays only
+    A = torch.from_numpy(np.ascontiguousarray(M.T @ M))
+    objective = allreduce_loop_sums(sums, b, A)            # ONE collective: sums + gradient + normal matrix
+    fid = orc.loop_fidelity(sps.csr_matrix(M), np.zeros(N * N), mism, np.arange(M.shape[0]), np.zeros(N * N), 1.0, 0.5)[0]
+    fid = allreduce_fidelity(torch.from_numpy(fid))
+    q.put((rank, sums.tolist(), b.numpy().copy(), A.numpy().copy(), fid.numpy().copy(), objective))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sums_one_collective():
+    """NEXT-2 over ranks: the gradient b = M' mismatch, the normal matrix and the misfit sums of a
+    theta-sharded iteration arrive through ONE all-reduce and equal the single-process values."""
+    import scipy.sparse as sps
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_loop, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ns, nd, N = 7, 12, 21
+    m = np.asfortranarray(orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2)[0])
+    c0 = np.asfortranarray(1.0 + 0.5 * (orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) - 1.0))
+    X, rho, M, st, _ = orc.forward_operator(orc.GridTables(c0, 1.5), m, 5e-2)
+    mism = (m[:, 4:8] - X).reshape(-1)
+    b, A = M.T @ mism, M.T @ M
+    fid = orc.loop_fidelity(sps.csr_matrix(M), np.zeros(N * N), mism, np.arange(M.shape[0]), np.zeros(N * N), 1.0, 0.5)[0]
+    for r in res:
+        assert abs(r[1][0] - mism @ mism) <= 1e-12 * (mism @ mism)
+        assert np.max(np.abs(r[2] - b)) <= 1e-12 * np.max(np.abs(b))
+        assert np.max(np.abs(r[3] - A)) <= 1e-12 * np.max(np.abs(A))
+        assert np.array_equal(r[4], fid)                   # max is exact
+        assert abs(r[5] - np.sqrt((mism @ mism) / (m[:, 4:8] ** 2).sum())) <= 1e-12
