@@ -865,13 +865,20 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     const int bt = block_threads(), wpb = bt / 64;
     unsigned nblk;
     if (a.init) {
-        // wave shape: 64 directions of one source by default; RAY_WAVE_DIRS=32/16/8 makes a wave a patch of
-        // 2/4/8 adjacent sources x that many directions (narrower fans: fewer distinct cells per wave)
-        static const int dshift = [] {
+        // wave shape: a patch of 2 adjacent sources x 32 directions by default (narrower fans touch fewer
+        // distinct cells per wave than 64 directions of one source: +3..7 % on every gridded workload,
+        // profiles/r1/ablations.md); fewer directions than that -> more sources per wave.
+        // RAY_WAVE_DIRS=64/32/16/8/4 overrides.
+        static const int env_dshift = [] {
             const char *e = getenv("RAY_WAVE_DIRS");
-            const int v = e ? atoi(e) : 64;
-            return v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 6;
+            const int v = e ? atoi(e) : 0;
+            return v == 64 ? 6 : v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 0;
         }();
+        int dshift = env_dshift;
+        if (!dshift) {
+            dshift = 5;
+            while (dshift > 2 && (1 << (dshift - 1)) >= a.nd) --dshift;
+        }
         a.dshift = dshift;
         const int spb = wpb << (6 - dshift), dpw = 1 << dshift;      // sources per block, directions per wave
         a.ngroup = (a.nsrc + spb - 1) / spb;
