@@ -240,21 +240,33 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     } while (__builtin_amdgcn_ballot_w64(dtl != 0.0) != 0 && it < a.max_steps);
     if (active) { st |= kStStepCap; t = tw; steps = it; }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
-        double lo = 0, hi = 1, mid = 0.5, E[4], e, P[4];
+        double lo = 0, hi = 1, mid = 0.5, E[4], P[4];
         int ib = 0;
         {
             const double2 p01 = s_park[threadIdx.x], p23 = s_park[256 + threadIdx.x];
             P[0] = p01.x; P[1] = p01.y; P[2] = p23.x; P[3] = p23.y;
         }
-        lerp4(E, P, X, mid);
-        e = norm2(E[0], E[1]) - 1;
-        while (__builtin_fabs(e) > 1e-15) {
+        // e = norm(E[1:2]) - 1, `abs(e) > 1e-15`, `e > 0` (NonObstacle.jl:84-88) decided on
+        // s = E1^2 + E2^2 without the square root: fl(sqrt(s)) is monotone in s, so each test is a
+        // comparison of s with the double where the rounded root crosses the threshold
+        // (tests/test_oracle.py::test_exit_bisection_thresholds derives and checks the three constants)
+        constexpr double kSL = 0x1.fffffffffffeep-1;     // smallest s with sqrt(s) - 1 >= -1e-15
+        constexpr double kSH = 0x1.0000000000009p+0;     // largest  s with sqrt(s) - 1 <=  1e-15
+        constexpr double kS1 = 0x1.0000000000001p+0;     // largest  s with sqrt(s) <= 1
+        double sq;
+        E[0] = (1 - mid) * P[0] + mid * X[0];
+        E[1] = (1 - mid) * P[1] + mid * X[1];
+        sq = E[0] * E[0] + E[1] * E[1];
+        while (sq < kSL || sq > kSH) {
             if (++ib > kBisectCap) { st |= kStBisectCap; break; }
-            if (e > 0) hi = mid; else lo = mid;
+            if (sq > kS1) hi = mid; else lo = mid;
             mid = (lo + hi) * 0.5;
-            lerp4(E, P, X, mid);
-            e = norm2(E[0], E[1]) - 1;
+            E[0] = (1 - mid) * P[0] + mid * X[0];
+            E[1] = (1 - mid) * P[1] + mid * X[1];
+            sq = E[0] * E[0] + E[1] * E[1];
         }
+        E[2] = (1 - mid) * P[2] + mid * X[2];
+        E[3] = (1 - mid) * P[3] + mid * X[3];
         t = a.time_unit ? t - (1 - mid) : t - (1 - mid) * dt;
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = E[k];
