@@ -356,8 +356,9 @@ __global__ __launch_bounds__(256) void k_merge_sort(int64_t *__restrict__ keys, 
     __syncthreads();
     for (int size = 2; size <= n2; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int sm = stride - 1;                                   // strides are powers of two
             for (int t = tid; t < (n2 >> 1); t += 256) {
-                const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+                const int lo = ((t & ~sm) << 1) | (t & sm), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const uint64_t x = sk[lo], y = sk[hi];
                 if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
