@@ -1554,9 +1554,9 @@ int ray_classify(ray_ctx *ctx, const double *m_host, int64_t ns, int64_t nd, int
 
 #ifdef RAY_STATS
 // instrumentation build only (scripts/): look-up statistics of the cell cache since the last call
-int ray_debug_stats(unsigned long long out[4])
+int ray_debug_stats(unsigned long long out[12])
 {
-    unsigned long long z[4] = {0, 0, 0, 0};
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     return RAY_OK;

@@ -151,7 +151,7 @@ __device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsi
 }
 
 #ifdef RAY_STATS
-__device__ unsigned long long g_ray_stats[4];   // [0] wave look-ups, [1] with >= 1 miss, [2] missing lanes, [3] wide-fan fetches
+__device__ unsigned long long g_ray_stats[12];   // [4] fetches, [5..9] fetches with > 21/32/42/48/53 runs, [10] sum of runs   // [0] wave look-ups, [1] with >= 1 miss, [2] missing lanes, [3] wide-fan fetches
 #endif
 
 // Tag slot of cell (i, j): (i + 37 j) mod 128 -- distinct for the cells of one wavefront (a compact arc
@@ -183,6 +183,18 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     const unsigned long long m1 = mask >> 1;
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
     const char *rec = reinterpret_cast<const char *>(g.rec);
+#ifdef RAY_STATS
+    if (a.lane == 0) {
+        const unsigned nr = npiece / 6u;
+        atomicAdd(&g_ray_stats[4], 1ull);
+        atomicAdd(&g_ray_stats[10], (unsigned long long)nr);
+        if (nr > 21) atomicAdd(&g_ray_stats[5], 1ull);
+        if (nr > 32) atomicAdd(&g_ray_stats[6], 1ull);
+        if (nr > 42) atomicAdd(&g_ray_stats[7], 1ull);
+        if (nr > 48) atomicAdd(&g_ray_stats[8], 1ull);
+        if (nr > 53) atomicAdd(&g_ray_stats[9], 1ull);
+    }
+#endif
     // the slots are about to be overwritten: forget what the tags said about them
     *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
     if (npiece > 6u * kRunSlots) {
@@ -333,11 +345,25 @@ __device__ __forceinline__ void h_from_record(const double X[4], double dx, doub
 // stage 2, the next step's stage 1 ~dt^2 from stage 4 -- so stages 2 and 4 FETCH, stages 3 and 1 LOOKUP.
 enum RecMode { kFetch = 0, kLookup = 1 };
 
+// `live`: this lane still integrates (its dt != 0).  A finished lane sits frozen at its exit point, far
+// from the fan, and would add a run of its own to every fetch until the whole wave is done: it looks
+// up the first live lane's cell instead.  What it computes from that record is multiplied by dt = 0.
 template <int AR, int MODE = kFetch>
-__device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob)
+__device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
+                                         bool live = true)
 {
-    const int i = cell_of<AR>(X[0], g, oob, a.nb_v);
-    const int j = cell_of<AR>(X[1], g, oob, a.nb_v);
+    int i = cell_of<AR>(X[0], g, oob, a.nb_v);
+    int j = cell_of<AR>(X[1], g, oob, a.nb_v);
+#ifndef RAY_ABLATE_NOGHOST
+    {
+        const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
+        if (lm != ~0ull && lm != 0ull) {                              // wave-uniform
+            const int first = __builtin_ctzll(lm);
+            const int i0 = __builtin_amdgcn_readlane(i, first), j0 = __builtin_amdgcn_readlane(j, first);
+            if (!live) { i = i0; j = j0; }
+        }
+    }
+#endif
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
 #ifdef RAY_ABLATE_PCOMP
     const double pi_ = __builtin_fma((double)i, g.h, g.p1), pj_ = __builtin_fma((double)j, g.h, g.p1);
@@ -399,9 +425,10 @@ struct MediumDev {
 };
 
 template <int MED, int AR, int MODE = kFetch>
-__device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob)
+__device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob,
+                                    bool live = true)
 {
-    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob);
+    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, live);
     else rhs_sinprod(m.sp, X, H);
 }
 
@@ -422,45 +449,46 @@ template <int MED, int AR, int FORM>
 __device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, OobMax &oob)
 {
     double H[4], Y[4], acc[4];
+    const bool live = dt != 0.0;
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }
