@@ -163,6 +163,9 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
  *   |v| <= droptol removed (the reference passes 1e-12; droptol < 0 keeps every stencil entry).
  * A Julia caller gets the reference's SparseMatrixCSC with
  *   copy(transpose(SparseMatrixCSC(N^2, 4num, indptr .+ 1, indices .+ 1, data)))  (julia/RayAMD.jl).
+ * The per-step stencil contributions pass through a device slab (480 B per ray-step); when that would
+ * exceed a quarter of the free memory (or 16 GB) the rays go through in chunks and the CSR pieces
+ * are concatenated -- the result is identical.
  * Limits: 4*num < 2^31; at most 1364 steps per ray (T/dt).  Parity is by tolerance: the reference
  * goes through LAPACK inv / BLAS gemm for rho and Phi.                                           */
 typedef struct ray_frechet ray_frechet;

@@ -5,6 +5,7 @@
 #include "ray_frechet.h"
 #include "ray_host_math.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1331,12 +1332,71 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         *out = f;
         return RAY_OK;
     }
-    rc = forward_operator_impl(ctx, med, m_host, num, ld, dt, droptol, X_host, ldx, rho_host, status, nsteps, f);
-    if (rc) {
-        (void)hipStreamSynchronize(ctx->stream);
-        ray_frechet_destroy(f);
-        return rc;
+    // The stencil slab needs 480 B per ray-step: rays go through in chunks (whole waves) that keep it
+    // within a budget, and the CSR pieces are concatenated (rows are ray-ordered, chunks contiguous).
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { ray_frechet_destroy(f); return fail(RAY_ERR_HIP, "hipMemGetInfo failed"); }
+    const char *env_slab = getenv("RAY_FRECHET_SLAB_MB");                 // tests force small chunks with it
+    const double env_mb = env_slab ? atof(env_slab) : 0.0;
+    const double budget = env_mb > 0 ? env_mb * 1048576.0 : std::min((double)free_b / 4, 16.0 * 1073741824.0);
+    std::vector<int64_t> cuts{0};
+    {
+        double acc = 0;
+        for (int64_t w0 = 0; w0 < num; w0 += 64) {
+            double tmax = 0;
+            for (int64_t r = w0; r < num && r < w0 + 64; ++r) tmax = std::max(tmax, m_host[r + 8 * ld] > 0 ? m_host[r + 8 * ld] : 0.0);
+            const double bytes = tmax > 0 ? (std::floor(tmax / dt) + 3) * 12 * 64 * 40.0 : 0.0;
+            if (acc > 0 && acc + bytes > budget) { cuts.push_back(w0); acc = 0; }
+            acc += bytes;
+        }
+        cuts.push_back(num);
     }
+    if (cuts.size() == 2) {
+        rc = forward_operator_impl(ctx, med, m_host, num, ld, dt, droptol, X_host, ldx, rho_host, status, nsteps, f);
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ray_frechet_destroy(f);
+            return rc;
+        }
+        *out = f;
+        return RAY_OK;
+    }
+    std::vector<ray_frechet *> pieces;
+    auto drop = [&]() { for (ray_frechet *q : pieces) ray_frechet_destroy(q); ray_frechet_destroy(f); };
+    int64_t nnz = 0;
+    for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+        const int64_t r0 = cuts[c], n = cuts[c + 1] - r0;
+        ray_frechet *q = new ray_frechet;
+        q->ctx = ctx; q->num = n; q->N = med->N;
+        pieces.push_back(q);
+        rc = forward_operator_impl(ctx, med, m_host + r0, n, ld, dt, droptol, X_host + r0, ldx,
+                                   rho_host ? rho_host + 16 * r0 : nullptr, status ? status + r0 : nullptr,
+                                   nsteps ? nsteps + r0 : nullptr, q);
+        if (rc) { (void)hipStreamSynchronize(ctx->stream); drop(); return rc; }
+        nnz += q->nnz;
+    }
+    hipError_t e = hipMalloc((void **)&f->d_indptr, sizeof(int64_t) * (size_t)(4 * num + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_indices, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_data, sizeof(double) * (size_t)(nnz ? nnz : 1));
+    int64_t at = 0;
+    for (size_t c = 0; e == hipSuccess && c < pieces.size(); ++c) {
+        ray_frechet *q = pieces[c];
+        const int64_t rows = 4 * q->num + (c + 1 == pieces.size() ? 1 : 0);       // the last piece also brings the end marker
+        hipLaunchKernelGGL(k_indptr_shift, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream,
+                           f->d_indptr + 4 * cuts[c], q->d_indptr, rows, at);
+        e = hipGetLastError();
+        if (e == hipSuccess && q->nnz) e = hipMemcpyAsync(f->d_indices + at, q->d_indices, sizeof(int32_t) * (size_t)q->nnz, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && q->nnz) e = hipMemcpyAsync(f->d_data + at, q->d_data, sizeof(double) * (size_t)q->nnz, hipMemcpyDeviceToDevice, ctx->stream);
+        at += q->nnz;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("ray_forward_operator (chunk assembly): ") + hipGetErrorString(e);
+        drop();
+        return fail(e == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, msg);
+    }
+    for (ray_frechet *q : pieces) ray_frechet_destroy(q);
+    f->nnz = nnz;
     *out = f;
     return RAY_OK;
 }

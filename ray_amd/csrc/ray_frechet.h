@@ -541,6 +541,13 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t *__restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
+// indptr of a row block appended behind `add` earlier non-zeros (chunked assembly)
+__global__ __launch_bounds__(256) void k_indptr_shift(int64_t *__restrict__ dst, const int64_t *__restrict__ src, int64_t n, int64_t add)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] + add;
+}
+
 // ---- NEXT-2: the reconstruction loop's passes over M (NonObstacle.jl:340-367) on the device CSR ----------
 __device__ __forceinline__ double wave_sum_f64(double v)
 {

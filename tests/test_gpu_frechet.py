@@ -168,3 +168,17 @@ def test_reconstruction_loop_passes(ctx, orc):
     assert np.array_equal(fid, fid_ref)                            # max is order-independent: exact
     assert (fid != fidelity).any()
     F.close()
+
+
+def test_forward_operator_chunked_equals_single(ctx, orc, monkeypatch):
+    """a slab budget of 1 MB forces several ray chunks: the concatenated CSR is identical."""
+    import ray_amd
+    c, tab, m = _data(orc, 61, 12, 40, 1)                         # 480 rays, 8 waves
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
+    monkeypatch.setenv("RAY_FRECHET_SLAB_MB", "1")
+    M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
+    assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
+    assert np.array_equal(M1.data, M2.data)
+    assert np.array_equal(s1, s2) and np.array_equal(i1["rho"], i2["rho"])
+    assert np.array_equal(i1["nsteps"], i2["nsteps"]) and np.array_equal(i1["status"], i2["status"])
