@@ -519,7 +519,24 @@ struct ray_ctx {
     bool timing = false;
     double kernel_ms = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    // grow-only device workspaces reused across calls (the Frechet stencil slab: a reconstruction loop
+    // calls ScatterForwardOperator every iteration with the same sizes)
+    void *ws[2] = {nullptr, nullptr};
+    size_t ws_cap[2] = {0, 0};
 };
+
+static hipError_t ctx_workspace(ray_ctx *ctx, int k, size_t bytes, void **out)
+{
+    if (bytes > ctx->ws_cap[k]) {
+        if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
+        ctx->ws[k] = nullptr; ctx->ws_cap[k] = 0;
+        hipError_t e = hipMalloc(&ctx->ws[k], bytes);
+        if (e != hipSuccess) return e;
+        ctx->ws_cap[k] = bytes;
+    }
+    *out = ctx->ws[k];
+    return hipSuccess;
+}
 
 struct ray_medium {
     ray_ctx *ctx = nullptr;
@@ -537,6 +554,11 @@ struct DevBuf {                                // scoped device allocation for h
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+struct BorrowedBuf {                           // same accessors as DevBuf, memory owned by the context
+    void *p;
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -687,6 +709,7 @@ int ray_ctx_destroy(ray_ctx *ctx)
     delete ctx->init;
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    for (int k = 0; k < 2; ++k) if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RAY_OK;
@@ -1240,10 +1263,12 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     if (slots * 40 * 2 + (size_t)num * 512 > free_b)
         return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the stencil slab does not fit in device memory (sum of T/dt too large); split the rays");
-    DevBuf dkeys, dvals, dm, dX, drho, dbase, dcap, ducnt, duoff, ducols, duvals, drowcnt;
+    DevBuf dm, dX, drho, dbase, dcap, ducnt, duoff, ducols, duvals, drowcnt;
     RayOutBufs ob_;
-    HIPCHK(dkeys.alloc((slots ? slots : 1) * sizeof(int64_t)));
-    HIPCHK(dvals.alloc((slots ? slots : 1) * 4 * sizeof(double)));
+    void *pkeys = nullptr, *pvals = nullptr;
+    HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * sizeof(int64_t), &pkeys));
+    HIPCHK(ctx_workspace(ctx, 1, (slots ? slots : 1) * 4 * sizeof(double), &pvals));
+    BorrowedBuf dkeys{pkeys}, dvals{pvals};
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
     HIPCHK(drho.alloc(sizeof(double) * 16 * (size_t)num));
