@@ -15,7 +15,7 @@ from ray_amd import device as rdev  # noqa: E402
 ctx = ray_amd.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 sp = ray_amd.SinProd.smooth_demo()
-N = 512
+N = int(os.environ.get("RAY_SHAPE_N", "512"))
 p = np.zeros(N)
 ray_amd._lib.check(ctx._lib.ray_linspace(-1.5, 1.5, N, p.ctypes.data))
 c = np.asfortranarray([[sp(float(x), float(y)) for y in p] for x in p])
@@ -30,5 +30,5 @@ for ns, nd in zip(args[0::2], args[1::2]):
             rdev.shoot_to_exit_dev(ctx, med, ns, nd, 1e-2, m.data_ptr(), num)
         torch.cuda.synchronize()
         cnt = ctx.counters(); ctx.enable_timing(False)
-    print(json.dumps({"ns": ns, "nd": nd, "kernel_ms": cnt["kernel_ms"] / cnt["launches"],
+    print(json.dumps({"grid": N, "ns": ns, "nd": nd, "kernel_ms": cnt["kernel_ms"] / cnt["launches"],
                       "ray_steps_per_s": cnt["ray_steps"] / (cnt["kernel_ms"] * 1e-3)}))
