@@ -184,15 +184,12 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
     if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {   // (live lanes <=> dtl != 0)
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
-#ifndef RAY_ABLATE_NOPARK
-        if (active)
-#else
-        if (active && it == 0)
-#endif
-        {
+#ifdef RAY_PARK_EVERY_STEP
+        if (active) {
             s_park[threadIdx.x] = make_double2(X[0], X[1]);
             s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
         }
+#endif
         double Xn[4];
         OobMax o = 0;
         rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, o);
@@ -203,6 +200,10 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         if (active) {
             oob |= (MED == kGrid ? oob_hit(a.med.g, o) : 0) | !(s == s);
             if (s >= 1.0) {
+#ifndef RAY_PARK_EVERY_STEP
+                s_park[threadIdx.x] = make_double2(X[0], X[1]);             // the pre-step state (`prev`)
+                s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
+#endif
                 t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
             } else if (OB == kObCircle) {
