@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         ++np;
     };
     if (PATH && valid) put(X[0], X[1]);                     // res = X[1:2]           Obstacle.jl:114
-    // pre-step state (NonObstacle.jl:71 `prev`) of every live lane, parked in LDS each step so that
-    // the step can update X in place; a lane stops writing when it exits, which leaves its pre-exit
-    // state there for the deferred bisection
+    // pre-step state (NonObstacle.jl:71 `prev`) of a lane at the step it leaves the disk, parked in LDS
+    // for the deferred bisection (registers would cost a wave per SIMD; the step itself updates X
+    // out of place only until the exit test)
     __shared__ double2 s_park[2 * 256];
     const double dt = a.dt;
     double dtl = valid ? dt : 0.0; // this lane's step: 0 once it has left (or is padding)
