@@ -171,10 +171,9 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         ++np;
     };
     if (PATH && valid) put(X[0], X[1]);                     // res = X[1:2]           Obstacle.jl:114
-    // pre-step state (NonObstacle.jl:71 `prev`) of a lane at the step it leaves the disk, parked in LDS
-    // for the deferred bisection (registers would cost a wave per SIMD; the step itself updates X
-    // out of place only until the exit test)
-    __shared__ double2 s_park[2 * 256];
+    // The pre-step state (NonObstacle.jl:71 `prev`) of a lane at the step it leaves the disk is parked in
+    // its output row (columns 5..8) until the deferred bisection picks it up: holding it in registers
+    // would cost a wave per SIMD, and LDS is spent on record slots.
     const double dt = a.dt;
     double dtl = valid ? dt : 0.0; // this lane's step: 0 once it has left (or is padding)
     double tw = 0, t = 0;          // tw: wave-uniform clock; t: this lane's, latched at its exit
@@ -184,12 +183,6 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
     if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {   // (live lanes <=> dtl != 0)
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
-#ifdef RAY_PARK_EVERY_STEP
-        if (active) {
-            s_park[threadIdx.x] = make_double2(X[0], X[1]);
-            s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
-        }
-#endif
         double Xn[4];
         OobMax o = 0;
         rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, o);
@@ -200,10 +193,8 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         if (active) {
             oob |= (MED == kGrid ? oob_hit(a.med.g, o) : 0) | !(s == s);
             if (s >= 1.0) {
-#ifndef RAY_PARK_EVERY_STEP
-                s_park[threadIdx.x] = make_double2(X[0], X[1]);             // the pre-step state (`prev`)
-                s_park[256 + threadIdx.x] = make_double2(X[2], X[3]);
-#endif
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];   // the pre-step state (`prev`)
                 t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
             } else if (OB == kObCircle) {
@@ -244,10 +235,8 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
         double lo = 0, hi = 1, mid = 0.5, E[4], P[4];
         int ib = 0;
-        {
-            const double2 p01 = s_park[threadIdx.x], p23 = s_park[256 + threadIdx.x];
-            P[0] = p01.x; P[1] = p01.y; P[2] = p23.x; P[3] = p23.y;
-        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[k] = a.m[r + (4 + k) * a.ld];
         // e = norm(E[1:2]) - 1, `abs(e) > 1e-15`, `e > 0` (NonObstacle.jl:84-88) decided on
         // s = E1^2 + E2^2 without the square root: fl(sqrt(s)) is monotone in s, so each test is a
         // comparison of s with the double where the rounded root crosses the threshold

@@ -51,14 +51,14 @@ __device__ __forceinline__ double div6(double a)
 
 // ---- per-thread access context for the gridded medium -----------------------------------------
 // LDS carve-up per workgroup (dynamic shared memory, see grid_lds_bytes()):
-//   [ p[0..N) node coordinates, padded to 512 B | per wave: 128 cell tags | per wave: 42 x 96-byte
+//   [ p[0..N) node coordinates, padded to 512 B | per wave: 128 cell tags | per wave: 64 x 96-byte
 //     record slots | per wave: 64 cell ids ]
 // The node table leaves the vector-memory path entirely; the record slots are the landing zone of
 // the wave-cooperative record fetch below, and the tags make them a small cell cache: a look-up at
 // a nearby position (the next RK4 stage moves a ray by ~1e-4 of a cell) finds its record there
 // without a new fetch.
-constexpr int kRunSlots = 42;                       // record slots per wave; wider fans take the per-lane path
-constexpr int kPasses = 4;                          // global_load_lds passes that fill them (4 x 1 KiB >= 42 x 96 B)
+constexpr int kRunSlots = 64;                       // record slots per wave: one per lane, never overflows
+constexpr int kPasses = 6;                          // global_load_lds passes that fill them (6 x 1 KiB = 64 x 96 B)
 constexpr int kWaveSlotBytes = kPasses * 1024;
 constexpr int kTagEntries = 128;                    // per wave, 4 bytes each: (cell id << 6) | slot, or kTagEmpty
 constexpr unsigned kTagEmpty = 0xffffffffu;
@@ -197,18 +197,6 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
 #endif
     // the slots are about to be overwritten: forget what the tags said about them
     *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
-    if (npiece > 6u * kRunSlots) {
-#ifdef RAY_STATS
-        if (a.lane == 0) atomicAdd(&g_ray_stats[3], 1ull);
-#endif
-        // a fan wider than the slots (> 42 distinct cells across 64 neighbouring rays, ~10 % of the
-        // fetches of the 2048^2 sweep): every lane gathers its own record, no cooperation.  (Serving
-        // the first 42 runs from the slots was tried: the extra live values cost more than it saves.)
-        const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)cid * 96u);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) out[k] = src[k];
-        return;
-    }
     if (leader) {
         *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
         *reinterpret_cast<unsigned *>(ray_smem + tag_addr(a, i, j)) = ((unsigned)cid << 6) | rank;
@@ -218,11 +206,20 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     asm volatile("" : "+v"(c0), "+v"(c1));                                   // keep the reads ahead of the masks
     dma_pass<0>(rec, a, c0, npiece);
     dma_pass<1>(rec, a, c1, npiece);
-    if (npiece > 128u) {                                                     // 22..42 runs: two more passes
+    if (npiece > 128u) {                                                     // wide fans: up to 4 more passes
         unsigned c2 = read_cell_of_pass<2>(a), c3 = read_cell_of_pass<3>(a);
         asm volatile("" : "+v"(c2), "+v"(c3));
         dma_pass<2>(rec, a, c2, npiece);
         dma_pass<3>(rec, a, c3, npiece);
+        if (npiece > 256u) {
+#ifdef RAY_STATS
+            if (a.lane == 0) atomicAdd(&g_ray_stats[3], 1ull);
+#endif
+            unsigned c4 = read_cell_of_pass<4>(a), c5 = read_cell_of_pass<5>(a);
+            asm volatile("" : "+v"(c4), "+v"(c5));
+            dma_pass<4>(rec, a, c4, npiece);
+            dma_pass<5>(rec, a, c5, npiece);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RAY_ABLATE_NOREAD
