@@ -24,3 +24,18 @@ def test_reconstruction_converges(ctx):
     err = [h["err"] for h in hist]
     assert all(b < a for a, b in zip(obj, obj[1:])), obj
     assert obj[-1] < 0.35 * obj[0] and err[-1] < 0.5 * err[0], (obj, err)
+
+
+def test_obstacle_workflow_converges(ctx):
+    """ObstacleDemo.jl:36-260 as a caller (examples/obstacle_reconstruction.py): reflections, ray
+    classification, unbroken rays, perc-masked reconstruction -- the objective must fall."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    spec = importlib.util.spec_from_file_location("recon_ob", os.path.join(ROOT, "examples", "obstacle_reconstruction.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    c0, hist, cls = mod.reconstruct(24, 120, 31, 8, ctx, log=lambda s: None)
+    obj = [h["obj"] for h in hist]
+    assert cls["unbroken"].size > 0 and cls["unbroken"].size < 24 * 120        # the obstacle breaks some fans
+    assert all(b < a for a, b in zip(obj, obj[1:])), obj
+    assert obj[-1] < 0.6 * obj[0], obj
