@@ -180,23 +180,27 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     int it = 0, steps = 0;         // it: wave-uniform step count
     int nref = 0, rfl = 0;
     bool active = valid;
-    // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below
-    if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {   // (live lanes <=> dtl != 0)
+    // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below.
+    // lm = the live lanes (dtl != 0), balloted once per step.  The raw cell indices are max-ed into `o`
+    // over ALL steps and judged when the lane leaves (or at the cap): what a finished lane adds to its
+    // own `o` afterwards is never looked at.  A NaN position never leaves and is judged at the cap.
+    unsigned long long lm = __builtin_amdgcn_ballot_w64(active);
+    OobMax o = 0;
+    if (lm != 0 && a.max_steps > 0) do {
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
         double Xn[4];
-        OobMax o = 0;
-        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, o);
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, lm, o);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
-            oob |= (MED == kGrid ? oob_hit(a.med.g, o) : 0) | !(s == s);
             if (s >= 1.0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];   // the pre-step state (`prev`)
                 t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
+                if (MED == kGrid) oob |= oob_hit(a.med.g, o);
             } else if (OB == kObCircle) {
                 if (ob_val(a.ob_r0, Xn[0], Xn[1]) <= 0 && rfl == 0) {            // Obstacle.jl:69-91
                     double lo = 0, hi = 1, mid = 0.5, E[4], e;
@@ -230,8 +234,12 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-    } while (__builtin_amdgcn_ballot_w64(dtl != 0.0) != 0 && it < a.max_steps);
-    if (active) { st |= kStStepCap; t = tw; steps = it; }
+        lm = __builtin_amdgcn_ballot_w64(dtl != 0.0);
+    } while (lm != 0 && it < a.max_steps);
+    if (active) {
+        st |= kStStepCap; t = tw; steps = it;
+        oob |= (MED == kGrid ? oob_hit(a.med.g, o) : 0) | !(X[0] == X[0]) | !(X[1] == X[1]);
+    }
     if (st & kStExited) {                                       // NonObstacle.jl:82-91
         double lo = 0, hi = 1, mid = 0.5, E[4], P[4];
         int ib = 0;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         }
         double Xn[4];
         OobMax o = 0;
-        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, o);
+        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o);
         ++it;
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {

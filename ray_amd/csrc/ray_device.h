@@ -158,7 +158,11 @@ __device__ unsigned long long g_ray_stats[12];   // [4] fetches, [5..9] fetches 
 // of at most a few tens of cells); a collision only costs the loser a miss.
 __device__ __forceinline__ unsigned tag_addr(const GridAcc &a, int i, int j)
 {
-    return ((mad24((unsigned)j, 37u * 4u, (unsigned)i << 2)) & (unsigned)(kTagEntries * 4 - 4)) | a.wtags;
+    unsigned t;                                   // spelled out: the compiler narrows __umul24 by a constant
+    asm("v_mad_u32_u24 %0, %1, 37, %2" : "=v"(t) : "v"(j), "v"(i));   // to a quarter-rate v_mul_lo_u32
+    unsigned addr;                                // and + lshl_add; left alone the compiler shifts first: 4 ops
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(t & (unsigned)(kTagEntries - 1)), "s"(a.wtags));
+    return addr;
 }
 
 __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6])
@@ -246,8 +250,9 @@ __device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &
     return;
 #endif
     const unsigned tag = *reinterpret_cast<const unsigned *>(ray_smem + tag_addr(a, i, j));
-    const bool hit = (tag >> 6) == (unsigned)cid;
-    const unsigned slot = hit ? (tag & 63u) : 0u;
+    const unsigned d = tag - ((unsigned)cid << 6);           // = slot on a hit, >= 64 otherwise (kTagEmpty included)
+    const bool hit = d < 64u;
+    const unsigned slot = d & 63u;                           // a missing lane reads some slot and overwrites it below
     const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(slot, 96u, a.wrec_v));
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = r[k];
@@ -342,23 +347,22 @@ __device__ __forceinline__ void h_from_record(const double X[4], double dx, doub
 // stage 2, the next step's stage 1 ~dt^2 from stage 4 -- so stages 2 and 4 FETCH, stages 3 and 1 LOOKUP.
 enum RecMode { kFetch = 0, kLookup = 1 };
 
-// `live`: this lane still integrates (its dt != 0).  A finished lane sits frozen at its exit point, far
+// `lm`: ballot of the lanes that still integrate (dt != 0), taken once per step by the caller.  A finished lane sits frozen at its exit point, far
 // from the fan, and would add a run of its own to every fetch until the whole wave is done: it looks
 // up the first live lane's cell instead.  What it computes from that record is multiplied by dt = 0.
 template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
-                                         bool live = true)
+                                         unsigned long long lm = ~0ull)
 {
     int i = cell_of<AR>(X[0], g, oob, a.nb_v);
     int j = cell_of<AR>(X[1], g, oob, a.nb_v);
 #ifndef RAY_ABLATE_NOGHOST
-    {
-        const unsigned long long lm = __builtin_amdgcn_ballot_w64(live);
-        if (lm != ~0ull && lm != 0ull) {                              // wave-uniform
-            const int first = __builtin_ctzll(lm);
-            const int i0 = __builtin_amdgcn_readlane(i, first), j0 = __builtin_amdgcn_readlane(j, first);
-            if (!live) { i = i0; j = j0; }
-        }
+    asm("" : "+s"(lm));               // compare afresh (s_cmp_lg_u64): a shared result comes back through a VGPR
+    if (lm != ~0ull) {                                                // wave-uniform: bit l = lane l is live
+        const int first = __builtin_ctzll(lm | (1ull << 63));
+        const int i0 = __builtin_amdgcn_readlane(i, first), j0 = __builtin_amdgcn_readlane(j, first);
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(i) : "v"(i0), "v"(i), "s"(lm));   // live ? own : first live lane's
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(j) : "v"(j0), "v"(j), "s"(lm));
     }
 #endif
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
@@ -423,9 +427,9 @@ struct MediumDev {
 
 template <int MED, int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob,
-                                    bool live = true)
+                                    unsigned long long lm = ~0ull)
 {
-    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, live);
+    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm);
     else rhs_sinprod(m.sp, X, H);
 }
 
@@ -443,49 +447,49 @@ __device__ __forceinline__ double fma_vop3(double a, double b, double c)
 // FORM 1 = a8/a9: k = H;    X + k/2*dt; (k1+2k2+2k3+k4)*dt/6.0    NonObstacle.jl:161-164,171
 // kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)
 template <int MED, int AR, int FORM>
-__device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt, OobMax &oob)
+__device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt,
+                                    unsigned long long lm, OobMax &oob)
 {
     double H[4], Y[4], acc[4];
-    const bool live = dt != 0.0;
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, live);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }
