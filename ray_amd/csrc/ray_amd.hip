@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     // own `o` afterwards is never looked at.  A NaN position never leaves and is judged at the cap.
     unsigned long long lm = __builtin_amdgcn_ballot_w64(active);
     OobMax o = 0;
+    RecState rs;
     if (lm != 0 && a.max_steps > 0) do {
         if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
         double Xn[4];
-        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, lm, o);
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, lm, o, rs);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     }
     double t = 0, dt = a.dt;
     bool active = valid && t < T;
+    RecState rs;
     // one back edge, one exit (wave-uniform); live lanes left at the cap get STEP_CAP below
     if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {
         double dtl = 0.0;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         }
         double Xn[4];
         OobMax o = 0;
-        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o);
+        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o, rs);
         ++it;
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {

@@ -75,6 +75,14 @@ struct GridAcc {
     unsigned role_poff[3];   // ... and 16 * ((lane + shift) % 6); see fetch_records()
 };
 
+// What a lane remembers of its last fetch_records(): the cell and where its record sits in the slots.
+// The look-up that follows a fetch (RK4 stage 3 after 2, the next stage 1 after 4) is for the SAME cell
+// in most lanes, and when that holds for the whole wave it reads the slot again without the tags.
+struct RecState {
+    int cid = -1;
+    unsigned addr = 0;
+};
+
 __host__ __device__ inline size_t grid_lds_bytes(int N, int block)
 {
     return (((size_t)N * 8 + 511) & ~(size_t)511) + (size_t)(block / 64) * kWaveLdsBytes;
@@ -151,7 +159,7 @@ __device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsi
 }
 
 #ifdef RAY_STATS
-__device__ unsigned long long g_ray_stats[12];   // [4] fetches, [5..9] fetches with > 21/32/42/48/53 runs, [10] sum of runs   // [0] wave look-ups, [1] with >= 1 miss, [2] missing lanes, [3] wide-fan fetches
+__device__ unsigned long long g_ray_stats[12];   // [4] fetches, [5..9] fetches with > 21/32/42/48/53 runs, [10] sum of runs   // [0] wave look-ups, [1] with >= 1 miss, [2] missing lanes, [3] wide-fan fetches, [11] look-ups served without the tags
 #endif
 
 // Tag slot of cell (i, j): (i + 37 j) mod 128 -- distinct for the cells of one wavefront (a compact arc
@@ -165,7 +173,7 @@ __device__ __forceinline__ unsigned tag_addr(const GridAcc &a, int i, int j)
     return addr;
 }
 
-__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6])
+__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
 {
 #ifdef RAY_ABLATE_NOFETCH
     asm volatile("" :: "v"(cid));
@@ -235,7 +243,9 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     asm volatile("" : "+v"(out[3].x), "+v"(out[3].y), "+v"(out[4].x), "+v"(out[4].y), "+v"(out[5].x), "+v"(out[5].y));
     return;
 #endif
-    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(rank, 96u, a.wrec_v));
+    rs.cid = cid;
+    rs.addr = mad24(rank, 96u, a.wrec_v);
+    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + rs.addr);
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = r[k];
 }
@@ -243,12 +253,21 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
 // Look-up through the tags (ALL 64 lanes together): the record of cell `cid` if the last
 // fetch_records() of this wave brought it in -- for this lane or for any other -- else this lane
 // gathers it from memory itself.  Same bytes either way: the path taken never shows in the results.
-__device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6])
+__device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
 {
 #if defined(RAY_ABLATE_NOFETCH) || defined(RAY_ABLATE_NOCACHE)
-    fetch_records(g, a, i, j, cid, out);
+    fetch_records(g, a, i, j, cid, out, rs);
     return;
 #endif
+    if (__builtin_amdgcn_ballot_w64(cid != rs.cid) == 0) {           // every lane still in the cell it fetched
+        const double2 *r = reinterpret_cast<const double2 *>(ray_smem + rs.addr);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = r[k];
+#ifdef RAY_STATS
+        if (a.lane == 0) { atomicAdd(&g_ray_stats[0], 1ull); atomicAdd(&g_ray_stats[11], 1ull); }
+#endif
+        return;
+    }
     const unsigned tag = *reinterpret_cast<const unsigned *>(ray_smem + tag_addr(a, i, j));
     const unsigned d = tag - ((unsigned)cid << 6);           // = slot on a hit, >= 64 otherwise (kTagEmpty included)
     const bool hit = d < 64u;
@@ -352,7 +371,7 @@ enum RecMode { kFetch = 0, kLookup = 1 };
 // up the first live lane's cell instead.  What it computes from that record is multiplied by dt = 0.
 template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
-                                         unsigned long long lm = ~0ull)
+                                         unsigned long long lm, RecState &rs)
 {
     int i = cell_of<AR>(X[0], g, oob, a.nb_v);
     int j = cell_of<AR>(X[1], g, oob, a.nb_v);
@@ -374,10 +393,10 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
 #endif
     double2 r[6];
 #ifdef RAY_ABLATE_HOT
-    fetch_records(g, a, i, j, (cid & 0xff) + 5000, r);     // same run structure, 256-record footprint: always L1-hot
+    fetch_records(g, a, i, j, (cid & 0xff) + 5000, r, rs);     // same run structure, 256-record footprint: always L1-hot
 #else
-    if (MODE == kLookup) lookup_records(g, a, i, j, cid, r);
-    else fetch_records(g, a, i, j, cid, r);
+    if (MODE == kLookup) lookup_records(g, a, i, j, cid, r, rs);
+    else fetch_records(g, a, i, j, cid, r, rs);
 #endif
     const double dx = X[0] - pi_, dy = X[1] - pj_;
     double c, gcX, gcY, tau;
@@ -427,9 +446,9 @@ struct MediumDev {
 
 template <int MED, int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob,
-                                    unsigned long long lm = ~0ull)
+                                    unsigned long long lm, RecState &rs)
 {
-    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm);
+    if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm, rs);
     else rhs_sinprod(m.sp, X, H);
 }
 
@@ -448,48 +467,48 @@ __device__ __forceinline__ double fma_vop3(double a, double b, double c)
 // kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)
 template <int MED, int AR, int FORM>
 __device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt,
-                                    unsigned long long lm, OobMax &oob)
+                                    unsigned long long lm, OobMax &oob, RecState &rs)
 {
     double H[4], Y[4], acc[4];
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm);
+        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }

@@ -24,5 +24,5 @@ ctx._lib.ray_debug_stats(out)
 steps = int(info["nsteps"].sum())
 print({"ray_steps": steps, "wave_lookups": out[0], "lookups_with_miss": out[1], "missing_lanes": out[2],
        "wide_fan_fetches": out[3], "miss_wave_frac": out[1] / max(out[0], 1),
-       "miss_lane_frac": out[2] / max(64 * out[0], 1), "fetches": out[4], "mean_runs": out[10] / max(out[4], 1),
+       "miss_lane_frac": out[2] / max(64 * out[0], 1), "fetches": out[4], "mean_runs": out[10] / max(out[4], 1), "same_cell_lookups": out[11],
        "frac_runs_gt_21_32_42_48_53": [round(out[k] / max(out[4], 1), 4) for k in (5, 6, 7, 8, 9)]})
