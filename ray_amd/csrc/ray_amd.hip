@@ -1294,7 +1294,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
     a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
     a.step_counter = ctx->d_steps;
-    const size_t lds = (((size_t)med->N * 8 + 15) & ~(size_t)15);
+    const size_t lds = frechet_lds_bytes(med->N);
     TimedSpan span(ctx);
     if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
     else hipLaunchKernelGGL(k_frechet<kExact>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
@@ -1302,18 +1302,32 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     // distinct nodes per ray
     int n2 = 256;
     while (n2 < frechet_entries(cap_max)) n2 <<= 1;
-    const size_t sort_lds = (size_t)n2 * sizeof(uint64_t);
-    if (sort_lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-    hipLaunchKernelGGL(k_merge_sort, dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
-                       dbase.as<int64_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>());
+    // 32-bit sort keys when node index and emission index fit together (N <= 724 at the largest n2 = 4096
+    // that leaves room, N <= 1448 at n2 <= 1024, ...); RAY_SORT_KEY=64 forces the wide keys
+    int eshift = 0;
+    while ((1 << eshift) < n2) ++eshift;
+    const char *env_key = getenv("RAY_SORT_KEY");                        // read per call: the tests switch it
+    const bool env_wide = env_key && atoi(env_key) == 64;
+    const bool narrow_key = !env_wide && eshift < 32 && (uint64_t)med->N * (uint64_t)med->N < (1ull << (32 - eshift)) - 1;
+    const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8);
+    if (narrow_key) {
+        if (sort_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL((k_merge_sort<256, uint32_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
+                           dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift);
+    } else {
+        if (sort_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL((k_merge_sort<256, uint64_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
+                           dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift);
+    }
     HIPCHK(hipGetLastError());
     int64_t U = 0;
     if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, duoff.as<int64_t>(), &U))) return rc;
     HIPCHK(ducols.alloc(sizeof(int32_t) * (size_t)(U ? U : 1)));
     HIPCHK(duvals.alloc(sizeof(double) * 4 * (size_t)(U ? U : 1)));
     hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, dkeys.as<int64_t>(), dvals.as<double>(),
-                       dbase.as<int64_t>(), ob_.ns.as<int32_t>(), drho.as<double>(), duoff.as<int64_t>(), droptol,
+                       dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), drho.as<double>(), duoff.as<int64_t>(), droptol,
                        ducols.as<int32_t>(), duvals.as<double>(), drowcnt.as<int32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMalloc((void **)&f->d_indptr, sizeof(int64_t) * (size_t)(4 * num + 1)));

@@ -5,8 +5,9 @@
 // The reference builds, per ray and per RK4 step, three 4 x N^2 sparse matrices (O(N^2) each) and a
 // dense 4num x N^2 SharedArray that it then compresses.  Here the sparse matrix is built on the device:
 //   k_frechet      one thread integrates (X, rho) of one ray and EMITS the 12-node stencil
-//                  contributions Theta = inv(rho) dV w of every trajectory node into a per-wave slab
-//                  [slot row][lane] (coalesced 8-byte keys, 32-byte values);
+//                  contributions Theta = inv(rho) dV w of every trajectory node into its ray's own
+//                  contiguous stretch of the slab (8-byte keys, 32-byte values): the merge kernels
+//                  read a ray's entries as one stream;
 //   k_merge_sort   one workgroup per ray sorts that ray's (node, emission order) keys in LDS and
 //                  ranks the distinct nodes;
 //   k_merge_emit   sums each node's contributions in emission order (the order of the reference's
@@ -156,10 +157,10 @@ struct FrechetArgs {
     double dt;
     int max_steps;
     double cease_r;
-    const int64_t *wave_base;   // slot-row offset of every wave (rows are 64 lanes wide)
-    const int32_t *wave_cap;    // step capacity of every wave (rows = 12 * (cap + 1))
-    int64_t *keys;              // [slot row][lane] node index (0-based, first index x) or -1
-    double *vals;               // [slot row][lane][4]
+    const int64_t *wave_base;   // slot-row offset of every wave (a wave owns 64 x rows entries from 64 * base)
+    const int32_t *wave_cap;    // step capacity of every wave (rows = 12 * (cap + 1) entries per ray)
+    int64_t *keys;              // [wave][lane][row] node index (0-based, first index x) or -1
+    double *vals;               // [wave][lane][row][4]
     double *X;                  // (num, 4) end states
     int64_t ldx;
     double *rho;                // (num, 16) final Jacobian, row-major
@@ -172,11 +173,24 @@ constexpr int kMergeMaxEntries = 16384; // per ray: 128 KiB of LDS keys
 
 __host__ __device__ inline int frechet_entries(int steps) { return steps > 0 ? (steps + 1) * kFrSlotsPerCall : 0; }
 
-// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> slot rows [row0, row0+12) of
-// this lane.  dV: NonObstacle.jl:107-139.
+// first slab entry of ray `lane` of a wave whose rays hold frechet_entries(cap) entries each
+__device__ __forceinline__ int64_t ray_slab0(int64_t wave_base, int cap, int lane)
+{
+    return wave_base * 64 + (int64_t)lane * frechet_entries(cap);
+}
+
+// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> entries [12 it, 12 it + 12) of
+// this lane's ray.  dV: NonObstacle.jl:107-139.  (ALL 64 lanes of the one-wave workgroup together.)
+// A ray's entries are contiguous in the slab, so lane-wise stores would touch 64 lines per
+// instruction: the wave transposes four entries per lane at a time through LDS (2 KB of keys, 8 KB
+// of values) and stores them as 16-byte pieces, consecutive lanes on consecutive pieces of one ray
+// (values: 8 lanes = one ray's 128 bytes).  Finished lanes' pieces are not stored: nobody reads them.
+constexpr int kFrStageBytes = 64 * 4 * 8 + 64 * 4 * 32;
+__host__ __device__ inline size_t frechet_lds_bytes(int N) { return (((size_t)N * 8 + 15) & ~(size_t)15) + kFrStageBytes; }
+
 template <int AR>
 __device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const double rho[16], double w,
-                                           bool live, int64_t row0, unsigned lane, int &oob)
+                                           bool live, int64_t wave_slab0, int rows, int it, unsigned lane, int &oob)
 {
     double H[4];
     PointEval q;
@@ -195,33 +209,58 @@ __device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[
     // node offsets relative to (i, j): cell nodes, x-neighbours (row 3), y-neighbours (row 4)
     const int di[12] = {0, 1, 0, 1, 2, -1, 2, -1, 0, 1, 0, 1};
     const int dj[12] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, -1, -1};
+    char *stage = ray_smem + (((size_t)N * 8 + 15) & ~(size_t)15);
+    int64_t *skeys = reinterpret_cast<int64_t *>(stage);                    // [lane][4]
+    double2 *svals = reinterpret_cast<double2 *>(stage + 64 * 4 * 8);       // [lane][4][2]
+    const unsigned long long lm = __ballot(live);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const int ni = q.i + di[k], nj = q.j + dj[k];
-        const bool ok = ni >= 0 && ni < N && nj >= 0 && nj < N;
-        o |= !ok;
-        double th[4];
-        if (k < 4) {
-            const double A0 = 2 * q.c * X[2] * phi[k], A1 = 2 * q.c * X[3] * phi[k];
-            const double A2 = -q.tau * q.gcX * phi[k] + ct2h * psi[k];
-            const double A3 = -q.tau * q.gcY * phi[k] + ct2h * gam[k];
+    for (int grp = 0; grp < 3; ++grp) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                th[r] = (((inv[r * 4] * A0 + inv[r * 4 + 1] * A1) + inv[r * 4 + 2] * A2) + inv[r * 4 + 3] * A3) * w;
-        } else if (k < 8) {
-            const double A2 = -ct2h * psi[k - 4];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = grp * 4 + kk;
+            const int ni = q.i + di[k], nj = q.j + dj[k];
+            const bool ok = ni >= 0 && ni < N && nj >= 0 && nj < N;
+            o |= !ok;
+            double th[4];
+            if (k < 4) {
+                const double A0 = 2 * q.c * X[2] * phi[k], A1 = 2 * q.c * X[3] * phi[k];
+                const double A2 = -q.tau * q.gcX * phi[k] + ct2h * psi[k];
+                const double A3 = -q.tau * q.gcY * phi[k] + ct2h * gam[k];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 2] * A2) * w;
-        } else {
-            const double A3 = -ct2h * gam[k - 8];
+                for (int r = 0; r < 4; ++r)
+                    th[r] = (((inv[r * 4] * A0 + inv[r * 4 + 1] * A1) + inv[r * 4 + 2] * A2) + inv[r * 4 + 3] * A3) * w;
+            } else if (k < 8) {
+                const double A2 = -ct2h * psi[k - 4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 3] * A3) * w;
+                for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 2] * A2) * w;
+            } else {
+                const double A3 = -ct2h * gam[k - 8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 3] * A3) * w;
+            }
+            skeys[lane * 4 + kk] = ok ? (int64_t)(ni + nj * N) : (int64_t)-1;
+            svals[(lane * 4 + kk) * 2] = make_double2(th[0], th[1]);
+            svals[(lane * 4 + kk) * 2 + 1] = make_double2(th[2], th[3]);
         }
-        const int64_t s = (row0 + k) * 64 + lane;
-        a.keys[s] = (live && ok) ? (int64_t)(ni + nj * N) : (int64_t)-1;
-        double2 *dst = reinterpret_cast<double2 *>(a.vals + s * 4);
-        dst[0] = make_double2(th[0], th[1]);
-        dst[1] = make_double2(th[2], th[3]);
+        __syncthreads();
+        const int64_t e0 = (int64_t)it * kFrSlotsPerCall + grp * 4;          // first entry of this group in a ray
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                                         // keys: 128 pieces, 2 per ray
+            const unsigned qq = t * 64 + lane, ray = qq >> 1, part = qq & 1;
+            if ((lm >> ray) & 1) {
+                const double2 piece = reinterpret_cast<const double2 *>(skeys)[qq];
+                *reinterpret_cast<double2 *>(a.keys + wave_slab0 + (int64_t)ray * rows + e0 + part * 2) = piece;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                                         // values: 512 pieces, 8 per ray
+            const unsigned qq = t * 64 + lane, ray = qq >> 3, part = qq & 7;
+            if ((lm >> ray) & 1) {
+                const double2 piece = svals[qq];
+                *reinterpret_cast<double2 *>(a.vals + (wave_slab0 + (int64_t)ray * rows + e0) * 4 + part * 2) = piece;
+            }
+        }
+        __syncthreads();
     }
     if (live) oob |= o;
 }
@@ -242,8 +281,9 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         for (int k = threadIdx.x; k < a.med.g.N; k += blockDim.x) p_lds[k] = a.med.g.p[k];
         __syncthreads();
     }
-    const int64_t base = a.wave_base[wave];
     const int cap = a.wave_cap[wave];
+    const int64_t wave_slab0 = ray_slab0(a.wave_base[wave], cap, 0);
+    const int rows = frechet_entries(cap);
     double X[4] = {0, 0, 1, 0}, T = 0;
     double rho[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int steps = 0, st = 0, oob = 0, it = 0;
@@ -265,7 +305,7 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
             t = t + dt;                                                      // :157
             dtl = dt;
         }
-        emit_theta<AR>(a, X, rho, wp + dtl * 0.5, active || fin, base + (int64_t)it * kFrSlotsPerCall, lane, oob);
+        emit_theta<AR>(a, X, rho, wp + dtl * 0.5, active || fin, wave_slab0, rows, it, lane, oob);
         fin = false;
         if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
@@ -332,11 +372,62 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
 // One workgroup per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power of
 // two); every entry gets the rank of its node among the ray's distinct nodes and is written back in
 // place as node << 40 | emission << 20 | rank; ucount[ray] = number of distinct nodes.
-__global__ __launch_bounds__(256) void k_merge_sort(int64_t *__restrict__ keys, const int64_t *__restrict__ wave_base,
-                                                    const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount)
+// The sort is LDS-bandwidth bound, so the compare-exchange passes with stride < 16 -- the last four of
+// every stage, and all of the first four stages -- run in registers on 16-key chunks: one LDS round
+// trip instead of four.  Keys sit padded by one per 16 (a thread's chunk is 136 bytes from its
+// neighbour's: conflict-free 8-byte reads).
+constexpr int kSortChunk = 16;
+__host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes) { return (size_t)(n2 + n2 / kSortChunk) * key_bytes; }
+__device__ __forceinline__ int spad(int i) { return i + (i >> 4); }
+
+// Sort keys.  64-bit: node << 40 | emission << 20.  32-bit (chosen by the host when the node index and
+// the emission index fit together: N^2 < 2^(32 - eshift), n2 <= 2^eshift): node << eshift | emission --
+// half the LDS traffic, one-instruction compares, min/max exchanges.
+template <typename K> struct SortKey;
+template <> struct SortKey<uint64_t> {
+    static __device__ __forceinline__ uint64_t dead() { return kKeyDead; }
+    static __device__ __forceinline__ uint64_t pack(int64_t node, int e, int) { return (uint64_t)node << 40 | (uint64_t)e << 20; }
+    static __device__ __forceinline__ uint64_t node(uint64_t k, int) { return k >> 40; }
+    static __device__ __forceinline__ uint64_t out(uint64_t k, int, int rank) { return k | (uint64_t)rank; }
+};
+template <> struct SortKey<uint32_t> {
+    static __device__ __forceinline__ uint32_t dead() { return 0xffffffffu; }
+    static __device__ __forceinline__ uint32_t pack(int64_t node, int e, int es) { return (uint32_t)node << es | (uint32_t)e; }
+    static __device__ __forceinline__ uint64_t node(uint32_t k, int es) { return k >> es; }
+    static __device__ __forceinline__ uint64_t out(uint32_t k, int es, int rank)
+    {
+        return (uint64_t)(k >> es) << 40 | (uint64_t)(k & ((1u << es) - 1u)) << 20 | (uint64_t)rank;
+    }
+};
+
+// strides min(size/2, 8) .. 1 of bitonic stage `size` on the chunk that starts at key c0
+template <typename K>
+__device__ __forceinline__ void sort_chunk_stage(K v[kSortChunk], int c0, int size)
 {
-    uint64_t *sk = reinterpret_cast<uint64_t *>(ray_smem);
-    __shared__ int s_cnt[256];
+#pragma unroll
+    for (int stride = kSortChunk / 2; stride > 0; stride >>= 1) {
+        if (stride < size) {
+#pragma unroll
+            for (int p = 0; p < kSortChunk / 2; ++p) {
+                const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1)), hi = lo + stride;
+                const bool up = ((c0 + lo) & size) == 0;
+                const K x = v[lo], y = v[hi];
+                const K mn = x < y ? x : y, mx = x < y ? y : x;
+                v[lo] = up ? mn : mx;
+                v[hi] = up ? mx : mn;
+            }
+        }
+    }
+}
+
+template <int BT, typename K>
+__global__ __launch_bounds__(BT) void k_merge_sort(int64_t *__restrict__ keys, const int64_t *__restrict__ wave_base,
+                                                    const int32_t *__restrict__ wave_cap,
+                                                    const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift)
+{
+    typedef SortKey<K> SK;
+    K *sk = reinterpret_cast<K *>(ray_smem);
+    __shared__ int s_cnt[BT];
     const int64_t ray = blockIdx.x;
     const int tid = threadIdx.x;
     const int ne = frechet_entries(nsteps[ray]);
@@ -346,56 +437,75 @@ __global__ __launch_bounds__(256) void k_merge_sort(int64_t *__restrict__ keys, 
     }
     int n2 = 256;
     while (n2 < ne) n2 <<= 1;
-    const int64_t base = wave_base[ray >> 6];
-    const int lane = (int)(ray & 63);
-    for (int e = tid; e < n2; e += 256) {
+    int64_t *rk = keys + ray_slab0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
+    for (int e = tid; e < n2; e += BT) {
         int64_t k = -1;
-        if (e < ne) k = keys[(base + e) * 64 + lane];
-        sk[e] = k < 0 ? kKeyDead : ((uint64_t)k << 40 | (uint64_t)e << 20);
+        if (e < ne) k = rk[e];
+        sk[spad(e)] = k < 0 ? SK::dead() : SK::pack(k, e, eshift);
     }
     __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    const int nchunk = n2 / kSortChunk;
+    for (int c = tid; c < nchunk; c += BT) {                       // stages 2, 4, 8, 16 entirely in registers
+        K v[kSortChunk];
+#pragma unroll
+        for (int j = 0; j < kSortChunk; ++j) v[j] = sk[c * (kSortChunk + 1) + j];
+#pragma unroll
+        for (int size = 2; size <= kSortChunk; size <<= 1) sort_chunk_stage<K>(v, c * kSortChunk, size);
+#pragma unroll
+        for (int j = 0; j < kSortChunk; ++j) sk[c * (kSortChunk + 1) + j] = v[j];
+    }
+    __syncthreads();
+    for (int size = 2 * kSortChunk; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride >= kSortChunk; stride >>= 1) {
             const int sm = stride - 1;                                   // strides are powers of two
-            for (int t = tid; t < (n2 >> 1); t += 256) {
+            for (int t = tid; t < (n2 >> 1); t += BT) {
                 const int lo = ((t & ~sm) << 1) | (t & sm), hi = lo + stride;
                 const bool up = (lo & size) == 0;
-                const uint64_t x = sk[lo], y = sk[hi];
-                if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+                const K x = sk[spad(lo)], y = sk[spad(hi)];
+                if ((x > y) == up) { sk[spad(lo)] = y; sk[spad(hi)] = x; }
             }
             __syncthreads();
         }
-    // rank of each entry's node: heads counted per contiguous chunk, scanned over the 256 threads
-    const int cs = n2 >> 8, e0 = tid * cs;
+        for (int c = tid; c < nchunk; c += BT) {
+            K v[kSortChunk];
+#pragma unroll
+            for (int j = 0; j < kSortChunk; ++j) v[j] = sk[c * (kSortChunk + 1) + j];
+            sort_chunk_stage<K>(v, c * kSortChunk, size);
+#pragma unroll
+            for (int j = 0; j < kSortChunk; ++j) sk[c * (kSortChunk + 1) + j] = v[j];
+        }
+        __syncthreads();
+    }
+    // rank of each entry's node: heads counted per contiguous chunk, scanned over the BT threads
+    const int cs = n2 / BT, e0 = tid * cs;
     int heads = 0;
     for (int e = e0; e < e0 + cs; ++e) {
-        const uint64_t k = sk[e];
-        heads += k != kKeyDead && (e == 0 || (sk[e - 1] >> 40) != (k >> 40));
+        const K k = sk[spad(e)];
+        heads += k != SK::dead() && (e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift));
     }
     s_cnt[tid] = heads;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
+    for (int off = 1; off < BT; off <<= 1) {
         const int v = tid >= off ? s_cnt[tid - off] : 0;
         __syncthreads();
         s_cnt[tid] += v;
         __syncthreads();
     }
     int rank = s_cnt[tid] - heads - 1;              // rank of the last head before this chunk
-    if (tid == 255) ucount[ray] = s_cnt[255];
-    uint64_t outk[1];
+    if (tid == BT - 1) ucount[ray] = s_cnt[BT - 1];
     for (int e = e0; e < e0 + cs; ++e) {
-        const uint64_t k = sk[e];
-        if (k == kKeyDead) { if (e < ne) keys[(base + e) * 64 + lane] = -1; continue; }
-        rank += (e == 0 || (sk[e - 1] >> 40) != (k >> 40));
-        outk[0] = k | (uint64_t)rank;
-        keys[(base + e) * 64 + lane] = (int64_t)outk[0];
+        const K k = sk[spad(e)];
+        if (k == SK::dead()) { if (e < ne) rk[e] = -1; continue; }
+        rank += (e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift));
+        rk[e] = (int64_t)SK::out(k, eshift, rank);
     }
 }
 
 // sums every distinct node's contributions in emission order, applies rho, writes the ray's block row
 // (ucols, uvals[4]) at uoff[ray] and the per-matrix-row entry counts that survive droptol.
 __global__ __launch_bounds__(256) void k_merge_emit(const int64_t *__restrict__ keys, const double *__restrict__ vals,
-                                                    const int64_t *__restrict__ wave_base, const int32_t *__restrict__ nsteps,
+                                                    const int64_t *__restrict__ wave_base, const int32_t *__restrict__ wave_cap,
+                                                    const int32_t *__restrict__ nsteps,
                                                     const double *__restrict__ rho, const int64_t *__restrict__ uoff,
                                                     double droptol, int32_t *__restrict__ ucols,
                                                     double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
@@ -406,30 +516,30 @@ __global__ __launch_bounds__(256) void k_merge_emit(const int64_t *__restrict__ 
     if (tid < 4) s_rows[tid] = 0;
     __syncthreads();
     const int ne = frechet_entries(nsteps[ray]);
-    const int64_t base = wave_base[ray >> 6];
-    const int lane = (int)(ray & 63);
+    const int64_t slab0 = ray_slab0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
+    const int64_t *rk = keys + slab0;
+    const double *rv = vals + slab0 * 4;
     const int64_t off = uoff[ray];
     double R[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) R[k] = rho[ray * 16 + k];
     int cnt[4] = {0, 0, 0, 0};
     for (int e = tid; e < ne; e += 256) {
-        const uint64_t k = (uint64_t)keys[(base + e) * 64 + lane];
+        const uint64_t k = (uint64_t)rk[e];
         if (k == kKeyDead) continue;
         const uint64_t node = k >> 40;
-        if (e > 0 && ((uint64_t)keys[(base + e - 1) * 64 + lane] >> 40) == node) continue;   // not a head
+        if (e > 0 && ((uint64_t)rk[e - 1] >> 40) == node) continue;                          // not a head
         double s[4] = {0, 0, 0, 0};
         uint64_t k2 = k;
         int e2 = e;
         bool first = true;
         do {
-            const int64_t slot = (base + (int64_t)((k2 >> 20) & 0xFFFFF)) * 64 + lane;
-            const double2 *p2 = reinterpret_cast<const double2 *>(vals + slot * 4);
+            const double2 *p2 = reinterpret_cast<const double2 *>(rv + (size_t)((k2 >> 20) & 0xFFFFF) * 4);
             const double2 lo = p2[0], hi = p2[1];
             if (first) { s[0] = lo.x; s[1] = lo.y; s[2] = hi.x; s[3] = hi.y; first = false; }
             else { s[0] += lo.x; s[1] += lo.y; s[2] += hi.x; s[3] += hi.y; }                 // Phi += Theta (:159,175)
             ++e2;
-            k2 = e2 < ne ? (uint64_t)keys[(base + e2) * 64 + lane] : kKeyDead;
+            k2 = e2 < ne ? (uint64_t)rk[e2] : kKeyDead;
         } while (k2 != kKeyDead && (k2 >> 40) == node);
         const int64_t u = off + (int64_t)(k & 0xFFFFF);
         double o4[4];

@@ -182,3 +182,19 @@ def test_forward_operator_chunked_equals_single(ctx, orc, monkeypatch):
     assert np.array_equal(M1.data, M2.data)
     assert np.array_equal(s1, s2) and np.array_equal(i1["rho"], i2["rho"])
     assert np.array_equal(i1["nsteps"], i2["nsteps"]) and np.array_equal(i1["status"], i2["status"])
+
+
+@pytest.mark.parametrize("N,ns,nd,dt", [(61, 6, 40, 2e-2), (75, 3, 70, 2e-2)])
+def test_forward_operator_sort_key_widths_agree(ctx, orc, monkeypatch, N, ns, nd, dt):
+    """k_merge_sort runs on 32-bit keys when node and emission index fit together and on 64-bit keys
+    otherwise: identical CSR either way (RAY_SORT_KEY=64 forces the wide keys)."""
+    import ray_amd
+    c, tab, m = _data(orc, N, ns, nd, 1, bump=0.3)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    monkeypatch.setenv("RAY_SORT_KEY", "64")
+    M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
+    assert np.array_equal(M1.data, M2.data) and np.array_equal(s1, s2)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+    assert np.max(np.abs(M1.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
