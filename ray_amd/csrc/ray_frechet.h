@@ -82,11 +82,9 @@ __device__ __forceinline__ double bil(double dx, double dy, double dxdy, double2
 
 // a3: H and Jm = dH/dX (row-major 4x4).                           NonObstacle.jl:6-28
 // M = [2*c*X[3:4]*g'  c^2*eye(2); -(c*h + g*g')*tau  -2*c*g*X[3:4]']
-template <int AR>
-__device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4], double H[4], double Jm[16], int &oob)
+// Jm from an evaluated point (the hess part of a3)
+__device__ __forceinline__ void jac_from_point(const GridDev &g, const double X[4], const PointEval &q, double Jm[16], int &oob)
 {
-    PointEval q;
-    point_eval<AR>(g, X, H, q, oob);
     // hess exists for I,J <= N-3 only: clamp + flag (reference: out-of-bounds read)
     const int ih = q.i < g.N - 4 ? q.i : g.N - 4, jh = q.j < g.N - 4 ? q.j : g.N - 4;
     oob |= (ih != q.i) | (jh != q.j);
@@ -107,6 +105,14 @@ __device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4]
             Jm[(2 + a) * 4 + b] = (-(c * hv[a][b] + gv[a] * gv[b])) * tau;
             Jm[(2 + a) * 4 + 2 + b] = ((-2 * c) * gv[a]) * X[2 + b];
         }
+}
+
+template <int AR>
+__device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4], double H[4], double Jm[16], int &oob)
+{
+    PointEval q;
+    point_eval<AR>(g, X, H, q, oob);
+    jac_from_point(g, X, q, Jm, oob);
 }
 
 __device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
@@ -189,13 +195,10 @@ constexpr int kFrStageBytes = 64 * 4 * 8 + 64 * 4 * 32;
 __host__ __device__ inline size_t frechet_lds_bytes(int N) { return (((size_t)N * 8 + 15) & ~(size_t)15) + kFrStageBytes; }
 
 template <int AR>
-__device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const double rho[16], double w,
+__device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const PointEval &q, int o,
+                                           const double rho[16], double w,
                                            bool live, int64_t wave_slab0, int rows, int it, unsigned lane, int &oob)
 {
-    double H[4];
-    PointEval q;
-    int o = 0;
-    point_eval<AR>(a.med.g, X, H, q, o);
     double inv[16];
     mat4_inv(rho, inv);
     const GridDev &g = a.med.g;
@@ -305,14 +308,19 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
             t = t + dt;                                                      // :157
             dtl = dt;
         }
-        emit_theta<AR>(a, X, rho, wp + dtl * 0.5, active || fin, wave_slab0, rows, it, lane, oob);
+        // the trajectory node X is evaluated once: for its emission and for RK4 stage 1
+        double k1[4];
+        PointEval q0;
+        int o0 = 0;
+        point_eval<AR>(a.med.g, X, k1, q0, o0);
+        emit_theta<AR>(a, X, q0, o0, rho, wp + dtl * 0.5, active || fin, wave_slab0, rows, it, lane, oob);
         fin = false;
         if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
-        double k1[4], H[4], Y[4], accx[4], Jm[16], V[16], R[16], accr[16];
-        int o = 0;
+        double H[4], Y[4], accx[4], Jm[16], V[16], R[16], accr[16];
+        int o = o0;
         const double hdt = 0.5 * dtl;
-        hamilton_jac<AR>(a.med.g, X, k1, Jm, o);
+        jac_from_point(a.med.g, X, q0, Jm, o);
         mat4_mul(Jm, rho, V);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = k1[k]; Y[k] = (AR == kFused) ? __builtin_fma(k1[k], hdt, X[k]) : X[k] + k1[k] * hdt; }
