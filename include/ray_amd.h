@@ -99,9 +99,13 @@ int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, doub
 int ray_medium_destroy(ray_medium *med);
 
 /* obstacle family (zero level set + normal).  CIRCLE: ob = sqrt(x^2+y^2) - r0, n = (x,y)/r
- * renormalised (ObstacleDemo.jl:20-34).                                                      */
-#define RAY_OB_NONE   0
-#define RAY_OB_CIRCLE 1
+ * renormalised (ObstacleDemo.jl:20-34 as shipped).  TREFOIL, the commented alternate of the same
+ * lines (the "cavity"): ob = r - (r0 - rho cos 3 theta) with rho = reserved[0] (ObstacleDemo.jl:23-24:
+ * r0 = 0.4, rho = 0.3) and n = [x,y]/r - 3 rho' sin(3 theta)/r [-y,x]/r renormalised with
+ * rho' = reserved[1] (:30-31: 0.2 -- the reference's normal carries a constant of its own, kept).  */
+#define RAY_OB_NONE    0
+#define RAY_OB_CIRCLE  1
+#define RAY_OB_TREFOIL 2
 typedef struct { int32_t kind; int32_t pad_; double r0; double reserved[2]; } ray_obstacle;
 
 #define RAY_TIME_SECONDS 0   /* t += dt, exit correction t -= (1-mid)*dt  (NonObstacle.jl:77,90) */

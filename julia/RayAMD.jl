@@ -11,7 +11,7 @@
 #
 # Only `ccall`; no AMDGPU.jl, no CUDA shims, no CPU fallback (a missing library is an error).
 # Closures cannot cross a C ABI onto a GPU: the medium / obstacle arguments are descriptor values
-# (SinProd, Circle) instead of Julia functions; pass the same value in the gradient slot.
+# (SinProd, Circle, Trefoil) instead of Julia functions; pass the same value in the gradient slot.
 #
 # STATUS: written for Julia >= 1.6.  Julia is not installed in the build image (and the reference
 # itself only parses on Julia 0.6), so this file has been syntax-reviewed but NOT executed; the
@@ -22,7 +22,7 @@ module RayAMD
 using SparseArrays
 using SharedArrays   # NonObstacleReconstruction requires m::SharedArray{Float64,2} (NonObstacle.jl:283)
 
-export SinProd, Circle, smooth_demo, obstacle_demo,
+export SinProd, Circle, Trefoil, trefoil_demo, smooth_demo, obstacle_demo,
        ScatterRelation, ScatterRelationObstacle, ScatterForwardOperator, NonReflectionTrace,
        misfit, set_arith!, ARITH_EXACT, ARITH_FUSED, read_rayfix
 
@@ -48,10 +48,17 @@ obstacle_demo() = SinProd(0.2, 2 * pi, 1.0 * pi, 2 * (0.2 * pi), 0.2 * pi)      
 struct Circle
     r0::Float64
 end
+"ob = r - (R - rho cos 3theta), normal with its own rho_n: the commented alternate of ObstacleDemo.jl:23-24,30-31"
+struct Trefoil
+    R::Float64; rho::Float64; rho_n::Float64
+end
+trefoil_demo() = Trefoil(0.4, 0.3, 0.2)
 
 struct CObstacle            # ray_obstacle
     kind::Int32; pad::Int32; r0::Float64; reserved1::Float64; reserved2::Float64
 end
+c_obstacle(ob::Circle)  = CObstacle(1, 0, ob.r0, 0.0, 0.0)
+c_obstacle(ob::Trefoil) = CObstacle(2, 0, ob.R, ob.rho, ob.rho_n)
 struct CShootParams         # ray_shoot_params
     ns::Int32; nd::Int32; src_begin::Int32; src_end::Int32
     dir_lo::Float64; dir_hi::Float64; dt::Float64
@@ -123,11 +130,11 @@ function ScatterRelation(c::SinProd, ∇c, ns::Int, nd::Int, dt::Float64, dir = 
 end
 
 # ---- Obstacle.jl:11 (column 9 in steps, the caller rescales: ObstacleDemo.jl:122,311) ---------------------
-function ScatterRelationObstacle(c::SinProd, ∇c, ob::Circle, ∇ob, ns::Int, nd::Int, dt::Float64)
+function ScatterRelationObstacle(c::SinProd, ∇c, ob::Union{Circle,Trefoil}, ∇ob, ns::Int, nd::Int, dt::Float64)
     same_or_nothing(c, ∇c, "medium"); same_or_nothing(ob, ∇ob, "obstacle")
     m = SharedArray{Float64}((ns * nd, 9))
     prm = CShootParams(ns, nd, 0, ns, 0.0, Float64(pi), dt, TIME_STEPS, 0)
-    cob = Ref(CObstacle(1, 0, ob.r0, 0.0, 0.0))
+    cob = Ref(c_obstacle(ob))
     with_medium(c) do med
         check(ccall((:ray_shoot_to_exit, LIB), Cint,
                     (Ptr{Cvoid}, Ptr{Cvoid}, Ref{CObstacle}, Ref{CShootParams}, Ptr{Cdouble}, Int64,

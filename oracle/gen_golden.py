@@ -1,6 +1,7 @@
 """Generates tests/golden/*.npz from the pure-Python restatement (oracle/ray_oracle.py).
 
-Run from the repo root:  python oracle/gen_golden.py
+Run from the repo root:  python oracle/gen_golden.py            (all fixtures)
+                         python oracle/gen_golden.py trefoil    (only the trefoil one, added later)
 The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
 path to the Python reading of the reference; the reference itself ships no vectors
 ("parity unpinned" by the reference).
@@ -24,8 +25,24 @@ def pack(rows, out):
                 nreflect=np.array([o[4] for o in out], dtype=np.int32))
 
 
+def trefoil():
+    # G1d: obstacle demo medium + the commented trefoil obstacle (ObstacleDemo.jl:23-24,30-31): cavities,
+    #      several reflections per ray
+    ns, nd, dt = 8, 16, 1e-2
+    so = P.SinProd.obstacle_demo()
+    rows = P.init_states(so, ns, nd, 0.0, pi)
+    tf = P.Trefoil(0.4, 0.3, 0.2)
+    np.savez(os.path.join(OUT, "scatter_trefoil_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt,
+             trefoil=np.array([tf.R, tf.rho, tf.rho_n]),
+             params=np.array([so.A, so.wx, so.wy, so.gx, so.gy]),
+             **pack(rows, P.shoot(so, rows, dt, obstacle=tf, time_unit=1)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["trefoil"]:
+        return trefoil()
+    trefoil()
     ns, nd, dt = 8, 16, 1e-2
 
     # G1a: smooth demo medium, analytic, ScatterRelation (NonObstacleDemo.jl:32)

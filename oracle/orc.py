@@ -22,7 +22,17 @@ class SinProd(C.Structure):
 
 
 class Obstacle(C.Structure):
-    _fields_ = [("kind", C.c_int), ("r0", C.c_double)]
+    _fields_ = [("kind", C.c_int), ("r0", C.c_double), ("rho_ob", C.c_double), ("rho_n", C.c_double)]
+
+
+def _obstacle(ob):
+    """None, a circle radius, or ("trefoil", R, rho, rho_n)."""
+    if ob is None:
+        return Obstacle(0, 0.0, 0.0, 0.0)
+    if isinstance(ob, tuple):
+        assert ob[0] == "trefoil"
+        return Obstacle(2, float(ob[1]), float(ob[2]), float(ob[3]))
+    return Obstacle(1, float(ob), 0.0, 0.0)
 
 
 class Medium(C.Structure):
@@ -144,7 +154,7 @@ def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=
     ns_ = np.zeros(num, dtype=np.int32)
     nr = np.zeros(num, dtype=np.int32)
     mm = _medium(med)
-    ob = Obstacle(0 if obstacle_r0 is None else 1, 0.0 if obstacle_r0 is None else obstacle_r0)
+    ob = _obstacle(obstacle_r0)
     lib().orc_shoot(C.byref(mm), C.byref(ob), C.c_double(dt), C.c_int(time_unit),
                     C.c_int(max_steps), _dp(m), C.c_int64(num), C.c_int64(num), _dp(st), _dp(ns_),
                     _dp(nr), C.c_int(nthreads))

@@ -289,16 +289,28 @@ void orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, doubl
 
 static double norm2(double a, double b) { return sqrt(a * a + b * b); }
 
-/* obstacle level set and normal (ObstacleDemo.jl:20-34, circle branch) */
+/* obstacle level set and normal (ObstacleDemo.jl:20-34): the shipped circle, and the commented
+ * trefoil alternate  r - (0.4 - rho cos(3 theta))  (:24)  with
+ * n = [x, y]/r - 3 rho sin(3 theta)/r * [-y, x]/r  (:31, a rho of its own), n/norm(n) (:33) */
 static double ob_val(const orc_obstacle *ob, double x, double y)
 {
+    if (ob->kind == 2) {
+        double theta = atan2(y, x);
+        double r = norm2(x, y);
+        return r - (ob->r0 - ob->rho_ob * cos(3 * theta));
+    }
     return norm2(x, y) - ob->r0;
 }
 static void ob_normal(const orc_obstacle *ob, double x, double y, double n[2])
 {
-    (void)ob;
     double r = norm2(x, y);
     double nx = x / r, ny = y / r;
+    if (ob->kind == 2) {
+        double theta = atan2(y, x);
+        double s = ((3 * ob->rho_n) * sin(3 * theta)) / r;      /* 3 * rho * sin(3 * theta)/r, left to right */
+        nx = nx - (s * (-y)) / r;
+        ny = ny - (s * x) / r;
+    }
     double nn = norm2(nx, ny);
     n[0] = nx / nn;
     n[1] = ny / nn;

@@ -42,8 +42,10 @@ extern "C" {
  * ObstacleDemo.jl:12,18    -> A=0.2 wx=2*pi wy=pi gx=2*(0.2*pi) gy=0.2*pi            */
 typedef struct { double A, wx, wy, gx, gy; } orc_sinprod;
 
-/* obstacle family: kind 0 none, 1 circle r - r0 (ObstacleDemo.jl:20-34) */
-typedef struct { int kind; double r0; } orc_obstacle;
+/* obstacle family: kind 0 none, 1 circle r - r0 (ObstacleDemo.jl:20-34 as shipped),
+ * 2 trefoil r - (r0 - rho_ob cos 3 theta) with the normal of ObstacleDemo.jl:31, which carries a rho of
+ * its own (the commented alternate, :23-24 rho = 0.3 and :30-31 rho = 0.2: the "cavity")       */
+typedef struct { int kind; double r0; double rho_ob, rho_n; } orc_obstacle;
 
 typedef struct {
     int kind;              /* 0 = sinprod analytic, 1 = grid tables */

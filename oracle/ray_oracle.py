@@ -11,7 +11,7 @@ Citations are file:line under /root/reference.  Indices below are 1-based where 
 are, to keep the reading literal; arrays are plain Python lists (column lists for m).
 """
 from fractions import Fraction
-from math import sin, cos, sqrt, floor, pi
+from math import sin, cos, sqrt, floor, pi, atan2
 
 ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED = 1, 2, 4, 8, 16
 BISECT_CAP = 200
@@ -65,6 +65,24 @@ class Circle:  # ObstacleDemo.jl:20-34
     def normal(self, x, y):
         r = sqrt(x * x + y * y)
         n = [x / r, y / r]
+        nn = sqrt(n[0] * n[0] + n[1] * n[1])
+        return [n[0] / nn, n[1] / nn]
+
+
+class Trefoil:  # the commented alternate of ObstacleDemo.jl:20-34
+    def __init__(self, R=0.4, rho=0.3, rho_n=0.2):
+        self.R, self.rho, self.rho_n = R, rho, rho_n
+
+    def ob(self, x, y):          # :21-24  r - (0.4 - rho * cos(3 * theta))
+        theta = atan2(y, x)
+        r = sqrt(x * x + y * y)
+        return r - (self.R - self.rho * cos(3 * theta))
+
+    def normal(self, x, y):      # :28-33  n = [x, y]/r - 3 * rho * sin(3 * theta)/r * [-y, x]/r; n/norm(n)
+        theta = atan2(y, x)
+        r = sqrt(x * x + y * y)
+        s = ((3 * self.rho_n) * sin(3 * theta)) / r
+        n = [x / r - (s * (-y)) / r, y / r - (s * x) / r]
         nn = sqrt(n[0] * n[0] + n[1] * n[1])
         return [n[0] / nn, n[1] / nn]
 

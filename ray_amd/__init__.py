@@ -13,7 +13,7 @@ CPU and there is no fallback.
     mismatch/objective/perc  NonObstacle.jl:336,372; ObstacleDemo.jl:219-226   misfit(m, obs)
 
 Function-valued arguments cannot reach a GPU through a C ABI, so `c`/`gradc` are a medium
-descriptor (SinProd) and `ob`/`gradob` an obstacle descriptor (Circle); pass the same object (or
+descriptor (SinProd) and `ob`/`gradob` an obstacle descriptor (Circle, Trefoil); pass the same object (or
 None) for the gradient slot.  Arrays are numpy float64 in Fortran order, laid out like the
 reference's m / s / c.
 """
@@ -131,6 +131,22 @@ class Circle:
 
     def _struct(self):
         return _lib.Obstacle(_lib.OB_CIRCLE, 0, self.r0, (C.c_double * 2)(0, 0))
+
+
+class Trefoil:
+    """ob = r - (R - rho cos 3 theta); normal [x,y]/r - 3 rho_n sin(3 theta)/r [-y,x]/r, renormalised: the
+    commented alternate obstacle of ObstacleDemo.jl:23-24 (R = 0.4, rho = 0.3) and :30-31 (rho_n = 0.2)
+    -- the reference's normal has a constant of its own, kept as a separate parameter."""
+
+    def __init__(self, R=0.4, rho=0.3, rho_n=0.2):
+        self.R, self.rho, self.rho_n = float(R), float(rho), float(rho_n)
+
+    @classmethod
+    def demo(cls):                 # ObstacleDemo.jl:23-24,30-31
+        return cls(0.4, 0.3, 0.2)
+
+    def _struct(self):
+        return _lib.Obstacle(_lib.OB_TREFOIL, 0, self.R, (C.c_double * 2)(self.rho, self.rho_n))
 
 
 class _Medium:

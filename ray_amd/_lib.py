@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("RAY_AMD_LIB") or os.path.join(_HERE, "libray_amd.so")
 
 RAY_OK = 0
 ST_EXITED, ST_STEP_CAP, ST_BISECT_CAP, ST_OOB, ST_CEASED = 0x01, 0x02, 0x04, 0x08, 0x10
-OB_NONE, OB_CIRCLE = 0, 1
+OB_NONE, OB_CIRCLE, OB_TREFOIL = 0, 1, 2
 TIME_SECONDS, TIME_STEPS = 0, 1
 TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT = 0, 1
 ARITH_EXACT, ARITH_FUSED = 0, 1

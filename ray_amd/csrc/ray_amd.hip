@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__
 struct ShootArgs {
     MediumDev med;
     int ob_kind;
-    double ob_r0;
+    double ob_r0, ob_rho, ob_rho_n;   // circle: r0; trefoil: R, rho of the level set, rho of the normal
     // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
     int init;
     int nd;
@@ -89,7 +89,33 @@ struct ShootArgs {
     int max_pts;
 };
 
-__device__ __forceinline__ double ob_val(double r0, double x, double y) { return norm2(x, y) - r0; }
+// obstacle level set and normal (ObstacleDemo.jl:20-34): the shipped circle  r - r0,  n = (x,y)/r, and the
+// commented trefoil alternate  r - (R - rho cos(3 theta))  (:24) with
+// n = [x,y]/r - 3 rho' sin(3 theta)/r * [-y,x]/r  (:31; rho' is a constant of its own there), n/norm(n) (:33)
+template <int OB>
+__device__ __forceinline__ double ob_val(const ShootArgs &a, double x, double y)
+{
+    if (OB == kObTrefoil) {
+        const double theta = atan2(y, x);
+        const double r = norm2(x, y);
+        return r - (a.ob_r0 - a.ob_rho * cos(3 * theta));
+    }
+    return norm2(x, y) - a.ob_r0;
+}
+template <int OB>
+__device__ __forceinline__ void ob_normal(const ShootArgs &a, double x, double y, double &nx, double &ny)
+{
+    const double r = norm2(x, y);
+    nx = x / r; ny = y / r;
+    if (OB == kObTrefoil) {
+        const double theta = atan2(y, x);
+        const double s = ((3 * a.ob_rho_n) * sin(3 * theta)) / r;
+        nx = nx - (s * (-y)) / r;
+        ny = ny - (s * x) / r;
+    }
+    const double nn = norm2(nx, ny);
+    nx = nx / nn; ny = ny / nn;
+}
 
 __device__ __forceinline__ void lerp4(double E[4], const double P[4], const double X[4], double mid)
 {
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     OobMax o = 0;
     RecState rs;
     if (lm != 0 && a.max_steps > 0) do {
-        if (OB == kObCircle) { if (active && ob_val(a.ob_r0, X[0], X[1]) > 0) rfl = 0; }   // Obstacle.jl:28-30
+        if (OB != kObNone) { if (active && ob_val<OB>(a, X[0], X[1]) > 0) rfl = 0; }        // Obstacle.jl:28-30
         double Xn[4];
         rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, lm, o, rs);
         ++it;
@@ -202,25 +228,23 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
                 t = tw; steps = it; dtl = 0.0;
                 st |= kStExited; active = false;
                 if (MED == kGrid) oob |= oob_hit(a.med.g, o);
-            } else if (OB == kObCircle) {
-                if (ob_val(a.ob_r0, Xn[0], Xn[1]) <= 0 && rfl == 0) {            // Obstacle.jl:69-91
+            } else if (OB != kObNone) {
+                if (ob_val<OB>(a, Xn[0], Xn[1]) <= 0 && rfl == 0) {              // Obstacle.jl:69-91
                     double lo = 0, hi = 1, mid = 0.5, E[4], e;
                     int ib = 0;
                     rfl = 1;
                     lerp4(E, X, Xn, mid);
-                    e = ob_val(a.ob_r0, E[0], E[1]);
+                    e = ob_val<OB>(a, E[0], E[1]);
                     while (__builtin_fabs(e) > 1e-15) {
                         if (++ib > kBisectCap) { st |= kStBisectCap; break; }
                         if (e > 0) lo = mid; else hi = mid;
                         mid = (lo + hi) * 0.5;
                         lerp4(E, X, Xn, mid);
-                        e = ob_val(a.ob_r0, E[0], E[1]);
+                        e = ob_val<OB>(a, E[0], E[1]);
                     }
                     // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
-                    const double rr = norm2(E[0], E[1]);
-                    double nx = E[0] / rr, ny = E[1] / rr;
-                    const double nn = norm2(nx, ny);
-                    nx = nx / nn; ny = ny / nn;
+                    double nx, ny;
+                    ob_normal<OB>(a, E[0], E[1], nx, ny);
                     const double a0 = 2 * nx, a1 = 2 * ny;
                     const double m11 = 1 - a0 * nx, m12 = 0 - a0 * ny;
                     const double m21 = 0 - a1 * nx, m22 = 1 - a1 * ny;
@@ -890,11 +914,15 @@ static size_t nodes_lds_bytes(const ray_medium *med)
 static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, ShootArgs &a)
 {
     const int obk = ob ? ob->kind : RAY_OB_NONE;
-    if (obk != RAY_OB_NONE && obk != RAY_OB_CIRCLE) return fail(RAY_ERR_UNSUPPORTED, "unknown obstacle kind");
+    if (obk != RAY_OB_NONE && obk != RAY_OB_CIRCLE && obk != RAY_OB_TREFOIL) return fail(RAY_ERR_UNSUPPORTED, "unknown obstacle kind");
     if (obk == RAY_OB_CIRCLE && !(ob->r0 > 0)) return fail(RAY_ERR_INVALID, "circle obstacle needs r0 > 0");
+    if (obk == RAY_OB_TREFOIL && !(ob->r0 > 0 && __builtin_fabs(ob->reserved[0]) < ob->r0))
+        return fail(RAY_ERR_INVALID, "trefoil obstacle needs R > |rho| (reserved[0]) so that the level set encloses the origin");
     a.med = medium_dev(med);
     a.ob_kind = obk;
     a.ob_r0 = ob ? ob->r0 : 0.0;
+    a.ob_rho = ob ? ob->reserved[0] : 0.0;
+    a.ob_rho_n = ob ? ob->reserved[1] : 0.0;
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
@@ -926,31 +954,24 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
     const bool fused = ctx->arith == RAY_ARITH_FUSED;
+#define RAY_LAUNCH_SHOOT(MED, OB, AR, PATH, LDS) hipLaunchKernelGGL((k_shoot<MED, OB, AR, PATH>), grid, block, LDS, ctx->stream, a)
+#define RAY_LAUNCH_BY_OB(MED, AR, PATH, LDS)                                  \
+    do {                                                                      \
+        if (obk == RAY_OB_NONE) RAY_LAUNCH_SHOOT(MED, kObNone, AR, PATH, LDS);  \
+        else if (obk == RAY_OB_CIRCLE) RAY_LAUNCH_SHOOT(MED, kObCircle, AR, PATH, LDS); \
+        else RAY_LAUNCH_SHOOT(MED, kObTrefoil, AR, PATH, LDS);                  \
+    } while (0)
     if (a.path) {
         if (med->kind == kGrid) {
-            if (obk == RAY_OB_NONE) {
-                if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kFused, 1>), grid, block, lds, ctx->stream, a);
-                else hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kExact, 1>), grid, block, lds, ctx->stream, a);
-            } else {
-                if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kFused, 1>), grid, block, lds, ctx->stream, a);
-                else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kExact, 1>), grid, block, lds, ctx->stream, a);
-            }
-        } else {
-            if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone, kExact, 1>), grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle, kExact, 1>), grid, block, 0, ctx->stream, a);
-        }
+            if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 1, lds);
+            else RAY_LAUNCH_BY_OB(kGrid, kExact, 1, lds);
+        } else RAY_LAUNCH_BY_OB(kSinProd, kExact, 1, 0);
     } else if (med->kind == kGrid) {
-        if (obk == RAY_OB_NONE) {
-            if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kFused>), grid, block, lds, ctx->stream, a);
-            else hipLaunchKernelGGL((k_shoot<kGrid, kObNone, kExact>), grid, block, lds, ctx->stream, a);
-        } else {
-            if (fused) hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kFused>), grid, block, lds, ctx->stream, a);
-            else hipLaunchKernelGGL((k_shoot<kGrid, kObCircle, kExact>), grid, block, lds, ctx->stream, a);
-        }
-    } else {
-        if (obk == RAY_OB_NONE) hipLaunchKernelGGL((k_shoot<kSinProd, kObNone, kExact>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_shoot<kSinProd, kObCircle, kExact>), grid, block, 0, ctx->stream, a);
-    }
+        if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 0, lds);
+        else RAY_LAUNCH_BY_OB(kGrid, kExact, 0, lds);
+    } else RAY_LAUNCH_BY_OB(kSinProd, kExact, 0, 0);
+#undef RAY_LAUNCH_BY_OB
+#undef RAY_LAUNCH_SHOOT
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)a.num;

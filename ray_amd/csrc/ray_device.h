@@ -35,7 +35,7 @@ struct GridDev {
 struct SinProdDev { double A, wx, wy, gx, gy; };
 
 enum MediumKind { kSinProd = 0, kGrid = 1 };
-enum ObstacleKind { kObNone = 0, kObCircle = 1 };
+enum ObstacleKind { kObNone = 0, kObCircle = 1, kObTrefoil = 2 };
 
 // correctly rounded a/b given rb = RN(1/b) (Markstein); see header comment
 __device__ __forceinline__ double div_rn(double a, double b, double rb)

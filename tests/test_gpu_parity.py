@@ -47,6 +47,22 @@ def assert_rays(m, info, ref_m, ref_st, ref_ns, ref_nr=None, exact=False):
         assert np.max(np.abs(m[:, 8] - ref_m[:, 8]) / np.maximum(1e-300, np.abs(ref_m[:, 8]))) <= RTOL
 
 
+def assert_rays_up_to_marginal_events(m, info, ref_m, ref_st, ref_ns, ref_nr, max_frac):
+    """Trefoil obstacle: its level set and normal go through atan2 / cos / sin -- the device library here,
+    libm in the oracle, last bits differ.  The reference's re-arming test `ob(X) > 0` (Obstacle.jl:28-30)
+    is evaluated ON the boundary right after a reflection (X = R with |ob(R)| <= 1e-15), so for a ray that
+    meets the obstacle again within the next step the sign of a rounding error decides whether it
+    reflects or passes: such rays are not defined by the reference beyond its own libm.  Everything else
+    must agree: identical events and values within RTOL; the marginal rays are few and all reflected."""
+    bad = (info["status"] != ref_st) | (info["nsteps"] != ref_ns) | (info["nreflect"] != ref_nr)
+    assert bad.mean() <= max_frac, "%d of %d rays classify differently" % (bad.sum(), bad.size)
+    assert np.all((ref_nr[bad] >= 1) & (info["nreflect"][bad] >= 1))
+    ok = ~bad
+    assert rel_err(m[ok, 0:8], ref_m[ok, 0:8]) <= RTOL
+    assert np.max(np.abs(m[ok, 8] - ref_m[ok, 8]) / np.maximum(1e-300, np.abs(ref_m[ok, 8]))) <= RTOL
+    return int(bad.sum())
+
+
 # ---- a4/a5: tables -------------------------------------------------------------------------
 @pytest.mark.parametrize("fixture", ["tables_n8.npz", "grid_n75_ns8_nd16.npz"])
 def test_tables_golden_bit_exact(ctx, fixture):
@@ -145,6 +161,52 @@ def test_scatter_obstacle_shipped_config(ctx, orc):
                                               ns, nd, dt, ctx=ctx, info=True)
     assert nrf.sum() > 1000
     assert_rays(m, info, ref, st, nst, nrf)
+
+
+def test_scatter_trefoil_golden(ctx):
+    """the commented trefoil obstacle of ObstacleDemo.jl:23-24,30-31 (cavities, double reflections)."""
+    import ray_amd
+    g = golden("scatter_trefoil_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd(*g["params"]), None,
+                                              ray_amd.Trefoil(*g["trefoil"]), None, int(g["ns"]),
+                                              int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert info["nreflect"].max() >= 2
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
+
+
+def test_scatter_trefoil_vs_oracle(ctx, orc):
+    """ObstacleDemo.jl's sweep (50 x 300, dt = 1e-2, t in steps) around the trefoil: identical events and
+    values within RTOL except for the marginal rays described in assert_rays_up_to_marginal_events
+    (measured: 14 of 15000, all with 1-4 reflections; the others agree to 6e-14)."""
+    import ray_amd
+    ns, nd, dt = 50, 300, 1e-2
+    tf = ("trefoil", 0.4, 0.3, 0.2)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=tf, time_unit=1, nthreads=8)
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ray_amd.Trefoil.demo(), None,
+                                              ns, nd, dt, ctx=ctx, info=True)
+    assert nrf.sum() > 1000 and nrf.max() >= 2
+    assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 2e-3)
+
+
+def test_grid_trefoil_vs_oracle(ctx, orc, arith):
+    """a7 loop with the trefoil over a gridded medium, from explicit states."""
+    import ray_amd
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, 129, 1.5)
+    tab = orc.GridTables(c, 1.5, arith)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ref, st, nst, nrf = orc.scatter_relation(tab, 16, 256, 1e-2, obstacle_r0=("trefoil", 0.4, 0.3, 0.2), time_unit=1, nthreads=8)
+    m2 = np.asfortranarray(ref.copy())
+    m2[:, 4:] = 0
+    info = ray_amd.shoot_states(med, m2, 1e-2, ob=ray_amd.Trefoil.demo(), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
+    assert nrf.sum() > 100
+    assert_rays_up_to_marginal_events(m2, info, ref, st, nst, nrf, 3e-3)
+
+
+def test_trefoil_bad_parameters(ctx):
+    import ray_amd
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ray_amd.Trefoil(0.2, 0.3, 0.2), None,
+                                        4, 8, 1e-2, ctx=ctx)
 
 
 def test_theta_block_equals_whole(ctx):
