@@ -43,6 +43,7 @@ def main():
     smooth, obst = ray_amd.SinProd.smooth_demo(), ray_amd.SinProd.obstacle_demo()
     gsmooth, gobst = grid_of(smooth), grid_of(obst)
     circle = ray_amd.Circle(0.3)
+    trefoil = ray_amd.Trefoil.demo()
 
     def shoot(med, ob, tu):
         return lambda: rdev.shoot_to_exit_dev(ctx, med, ns, nd, 1e-2, m.data_ptr(), num, ob=ob, time_unit=tu,
@@ -74,6 +75,8 @@ def main():
     run("shoot analytic smooth (NonObstacleDemo medium)", shoot(smooth, None, 0))
     run("shoot analytic obstacle circle0.3 (ObstacleDemo workload)", shoot(obst, circle, 1))
     run("shoot grid512 obstacle circle0.3", shoot(gobst, circle, 1))
+    run("shoot analytic obstacle trefoil 0.4/0.3/0.2 (ObstacleDemo.jl:23-24 alternate, cavities)", shoot(obst, trefoil, 1))
+    run("shoot grid512 obstacle trefoil", shoot(gobst, trefoil, 1))
     # a9/a8: trace the smooth data on the grid for its own traveltimes at the reconstruction step 5e-2
     ctx.set_arith(ray_amd.ARITH_FUSED)
     shoot(gsmooth, None, 0)()
