@@ -48,8 +48,8 @@ def assert_rays(m, info, ref_m, ref_st, ref_ns, ref_nr=None, exact=False):
 
 
 def assert_rays_up_to_marginal_events(m, info, ref_m, ref_st, ref_ns, ref_nr, max_frac):
-    """Trefoil obstacle: its level set and normal go through atan2 / cos / sin -- the device library here,
-    libm in the oracle, last bits differ.  The reference's re-arming test `ob(X) > 0` (Obstacle.jl:28-30)
+    """Trefoil obstacle: its level set and normal go through cos / sin of 3 atan2(y, x) -- libm in the oracle,
+    triple-angle identities on x/r, y/r in the kernel (ray_amd.hip ob_val): last bits differ, as between two libms.  The reference's re-arming test `ob(X) > 0` (Obstacle.jl:28-30)
     is evaluated ON the boundary right after a reflection (X = R with |ob(R)| <= 1e-15), so for a ray that
     meets the obstacle again within the next step the sign of a rounding error decides whether it
     reflects or passes: such rays are not defined by the reference beyond its own libm.  Everything else
