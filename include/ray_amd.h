@@ -96,6 +96,12 @@ int ray_medium_export_tables(ray_medium *med, double *eval_host, double *grad_ho
  * ObstacleDemo.jl:12,18 = (0.2, 2pi, pi, 2(0.2pi), 0.2pi).                                   */
 int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, double gx, double gy,
                               ray_medium **out);
+/* Second analytic family, the commented alternates of the demos:  c = 1 + sum_k a_k sin(pi r_k),
+ * r_k = |(x,y) - (x_k,y_k)|,  grad c = sum_k a_k pi cos(pi r_k)/r_k [(x - x_k), (y - y_k)], K <= 4.
+ * NonObstacleDemo.jl:7-11,15-22 = a (0.2,0.4,0.2,0.3), centres (0.5,0.2) (-0.4,-0.3) (0.3,-0.4) (-0.2,0.1);
+ * ObstacleDemo.jl:9-11,15-17 = a (0.4,0.4), centres (0.5,0.2) (-0.4,-0.3).                            */
+int ray_medium_create_radial(ray_ctx *ctx, int K, const double *a, const double *xk, const double *yk,
+                             ray_medium **out);
 int ray_medium_destroy(ray_medium *med);
 
 /* obstacle family (zero level set + normal).  CIRCLE: ob = sqrt(x^2+y^2) - r0, n = (x,y)/r

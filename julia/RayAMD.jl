@@ -22,7 +22,7 @@ module RayAMD
 using SparseArrays
 using SharedArrays   # NonObstacleReconstruction requires m::SharedArray{Float64,2} (NonObstacle.jl:283)
 
-export SinProd, Circle, Trefoil, trefoil_demo, smooth_demo, obstacle_demo,
+export SinProd, RadialSineSum, smooth_alt, obstacle_alt, Circle, Trefoil, trefoil_demo, smooth_demo, obstacle_demo,
        ScatterRelation, ScatterRelationObstacle, ScatterForwardOperator, NonReflectionTrace,
        misfit, set_arith!, ARITH_EXACT, ARITH_FUSED, read_rayfix
 
@@ -43,6 +43,15 @@ end
 smooth_demo()   = SinProd(0.3, 1.5 * pi, 1.5 * pi, 0.45 * pi, 0.45 * pi)          # NonObstacleDemo.jl:12,23
 obstacle_demo() = SinProd(0.2, 2 * pi, 1.0 * pi, 2 * (0.2 * pi), 0.2 * pi)         # ObstacleDemo.jl:12,18
 (s::SinProd)(x, y) = 1 + s.A * sin(s.wx * x) * sin(s.wy * y)                       # waveSpeed(x, y)
+
+"c = 1 + sum a_k sin(pi |x - x_k|): the commented alternate media (NonObstacleDemo.jl:7-11; ObstacleDemo.jl:9-11)"
+struct RadialSineSum
+    a::Vector{Float64}; x::Vector{Float64}; y::Vector{Float64}
+end
+smooth_alt()   = RadialSineSum([0.2, 0.4, 0.2, 0.3], [0.5, -0.4, 0.3, -0.2], [0.2, -0.3, -0.4, 0.1])
+obstacle_alt() = RadialSineSum([0.4, 0.4], [0.5, -0.4], [0.2, -0.3])
+(s::RadialSineSum)(x, y) = 1.0 + sum(s.a[k] * sin(pi * sqrt((x - s.x[k])^2 + (y - s.y[k])^2)) for k in 1:length(s.a))
+const Analytic = Union{SinProd,RadialSineSum}
 
 "ob = sqrt(x^2+y^2) - r0 (ObstacleDemo.jl:20-34)"
 struct Circle
@@ -99,6 +108,18 @@ function with_medium(f, c::SinProd)
     end
 end
 
+function with_medium(f, c::RadialSineSum)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_medium_create_radial, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+                context(), length(c.a), c.a, c.x, c.y, h))
+    try
+        f(h[])
+    finally
+        ccall((:ray_medium_destroy, LIB), Cint, (Ptr{Cvoid},), h[])
+    end
+end
+
 function with_medium(f, c::Matrix{Float64}, ext::Float64)
     N = size(c, 1)
     size(c, 2) == N || error("c must be N x N")
@@ -116,7 +137,7 @@ same_or_nothing(a, b, what) = (b === nothing || b === a || b == a) ||
     error("pass the $what descriptor itself (or nothing) in the gradient slot: closures cannot cross the C ABI")
 
 # ---- NonObstacle.jl:54 ----------------------------------------------------------------------------------
-function ScatterRelation(c::SinProd, ∇c, ns::Int, nd::Int, dt::Float64, dir = (0, pi))
+function ScatterRelation(c::Analytic, ∇c, ns::Int, nd::Int, dt::Float64, dir = (0, pi))
     same_or_nothing(c, ∇c, "medium")
     m = SharedArray{Float64}((ns * nd, 9))
     prm = CShootParams(ns, nd, 0, ns, Float64(dir[1]), Float64(dir[2]), dt, TIME_SECONDS, 0)
@@ -130,7 +151,7 @@ function ScatterRelation(c::SinProd, ∇c, ns::Int, nd::Int, dt::Float64, dir = 
 end
 
 # ---- Obstacle.jl:11 (column 9 in steps, the caller rescales: ObstacleDemo.jl:122,311) ---------------------
-function ScatterRelationObstacle(c::SinProd, ∇c, ob::Union{Circle,Trefoil}, ∇ob, ns::Int, nd::Int, dt::Float64)
+function ScatterRelationObstacle(c::Analytic, ∇c, ob::Union{Circle,Trefoil}, ∇ob, ns::Int, nd::Int, dt::Float64)
     same_or_nothing(c, ∇c, "medium"); same_or_nothing(ob, ∇ob, "obstacle")
     m = SharedArray{Float64}((ns * nd, 9))
     prm = CShootParams(ns, nd, 0, ns, 0.0, Float64(pi), dt, TIME_STEPS, 0)

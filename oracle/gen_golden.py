@@ -2,6 +2,7 @@
 
 Run from the repo root:  python oracle/gen_golden.py            (all fixtures)
                          python oracle/gen_golden.py trefoil    (only the trefoil one, added later)
+                         python oracle/gen_golden.py radial     (only the radial-sine-sum ones, added later)
 The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
 path to the Python reading of the reference; the reference itself ships no vectors
 ("parity unpinned" by the reference).
@@ -38,11 +39,26 @@ def trefoil():
              **pack(rows, P.shoot(so, rows, dt, obstacle=tf, time_unit=1)))
 
 
+def radial():
+    # G1e: the commented alternate media (NonObstacleDemo.jl:7-11,15-22 four terms, ScatterRelation;
+    #      ObstacleDemo.jl:9-11,15-17 two terms with the shipped circle, ScatterRelationObstacle)
+    ns, nd, dt = 8, 16, 1e-2
+    for name, med, ob, tu in (("smooth", P.RadialSineSum.smooth_alt(), None, 0),
+                              ("obstacle", P.RadialSineSum.obstacle_alt(), P.Circle(0.3), 1)):
+        rows = P.init_states(med, ns, nd, 0.0, pi)
+        np.savez(os.path.join(OUT, "scatter_radial_%s_ns8_nd16.npz" % name), ns=ns, nd=nd, dt=dt,
+                 terms=np.array(med.terms), r0=0.3 if ob else 0.0, time_unit=tu,
+                 **pack(rows, P.shoot(med, rows, dt, obstacle=ob, time_unit=tu)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["trefoil"]:
         return trefoil()
+    if sys.argv[1:] == ["radial"]:
+        return radial()
     trefoil()
+    radial()
     ns, nd, dt = 8, 16, 1e-2
 
     # G1a: smooth demo medium, analytic, ScatterRelation (NonObstacleDemo.jl:32)

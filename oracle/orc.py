@@ -35,9 +35,14 @@ def _obstacle(ob):
     return Obstacle(1, float(ob), 0.0, 0.0)
 
 
+class Radial(C.Structure):
+    _fields_ = [("K", C.c_int), ("a", C.c_double * 4), ("x", C.c_double * 4), ("y", C.c_double * 4)]
+
+
 class Medium(C.Structure):
     _fields_ = [("kind", C.c_int), ("sp", SinProd), ("N", C.c_int), ("ext", C.c_double),
-                ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p), ("arith", C.c_int)]
+                ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p), ("arith", C.c_int),
+                ("rad", Radial)]
 
 
 def build():
@@ -127,7 +132,37 @@ def analytic_medium(params):
     return m
 
 
+# the commented alternates: (a_k, x_k, y_k) terms of c = 1 + sum a_k sin(pi |x - x_k|)
+SMOOTH_ALT = ((0.2, 0.5, 0.2), (0.4, -0.4, -0.3), (0.2, 0.3, -0.4), (0.3, -0.2, 0.1))     # NonObstacleDemo.jl:7-11
+OBSTACLE_ALT = ((0.4, 0.5, 0.2), (0.4, -0.4, -0.3))                                       # ObstacleDemo.jl:9-11
+
+
+def radial_medium(terms):
+    m = Medium()
+    m.kind = 2
+    m.rad.K = len(terms)
+    for k, (a, x, y) in enumerate(terms):
+        m.rad.a[k], m.rad.x[k], m.rad.y[k] = a, x, y
+    return m
+
+
+def radial_grid(terms, N, ext):
+    """c[i,j] = waveSpeed(p[i], p[j]) for the radial family, Fortran order (N,N)."""
+    p = linspace(-ext, ext, N)
+    c = np.empty((N, N), order="F")
+    for i in range(N):
+        for j in range(N):
+            v = 1.0
+            for a, xk, yk in terms:
+                dx, dy = float(p[i]) - xk, float(p[j]) - yk
+                v = v + a * math.sin(math.pi * math.sqrt(dx * dx + dy * dy))
+            c[i, j] = v
+    return c
+
+
 def _medium(med):
+    if isinstance(med, tuple) and med and isinstance(med[0], tuple):
+        return radial_medium(med)
     if isinstance(med, GridTables):
         return med.medium()
     if isinstance(med, Medium):

@@ -255,9 +255,48 @@ void orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4])
     H[3] = ((-tau) * g1) * speed;
 }
 
+/* a12 alternates (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), left to right as written:
+ *   1.0 + 0.2 * sin(pi * r) + 0.4 * sin(pi * v) + ...
+ *   0.2 * pi * cos(pi * r)/r * [(x-0.5), (y-0.2)] + 0.4 * pi * cos(pi * v)/v * [...] + ...        */
+static double radial_c(const orc_radial *rd, double x, double y)
+{
+    double c = 1.0;
+    for (int k = 0; k < rd->K; ++k) {
+        double dx = x - rd->x[k], dy = y - rd->y[k];
+        double r = sqrt(dx * dx + dy * dy);
+        c = c + rd->a[k] * sin(M_PI * r);
+    }
+    return c;
+}
+static void radial_grad(const orc_radial *rd, double x, double y, double g[2])
+{
+    g[0] = g[1] = 0;
+    for (int k = 0; k < rd->K; ++k) {
+        double dx = x - rd->x[k], dy = y - rd->y[k];
+        double r = sqrt(dx * dx + dy * dy);
+        double f = ((rd->a[k] * M_PI) * cos(M_PI * r)) / r;
+        if (k == 0) { g[0] = f * dx; g[1] = f * dy; }
+        else { g[0] = g[0] + f * dx; g[1] = g[1] + f * dy; }
+    }
+}
+/* a1: Hamilton (NonObstacle.jl:1-4) with those closures */
+void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
+{
+    double speed = radial_c(rd, X[0], X[1]);
+    double g[2];
+    radial_grad(rd, X[0], X[1], g);
+    double tau = X[2] * X[2] + X[3] * X[3];
+    double s2 = speed * speed;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = ((-tau) * g[0]) * speed;
+    H[3] = ((-tau) * g[1]) * speed;
+}
+
 static int rhs(const orc_medium *med, const double X[4], double H[4])
 {
     if (med->kind == 0) { orc_hamilton_sinprod(X, &med->sp, H); return 0; }
+    if (med->kind == 2) { orc_hamilton_radial(X, &med->rad, H); return 0; }
     return orc_discrete_hamilton(X, med->eval, med->grad, med->p, med->N, H);
 }
 
@@ -273,6 +312,7 @@ void orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, doubl
         double sx = cos(source[i]), sy = sin(source[i]);
         int oob = 0;
         double cs = med->kind == 0 ? sinprod_c(&med->sp, sx, sy)
+                  : med->kind == 2 ? radial_c(&med->rad, sx, sy)
                                    : grid_speed(sx, sy, med->eval, med->p, med->N, &oob);
         for (int j = 0; j < nd; ++j) {
             double theta = source[i] + M_PI * 0.5 + direct[j + 1];

@@ -47,12 +47,19 @@ typedef struct { double A, wx, wy, gx, gy; } orc_sinprod;
  * its own (the commented alternate, :23-24 rho = 0.3 and :30-31 rho = 0.2: the "cavity")       */
 typedef struct { int kind; double r0; double rho_ob, rho_n; } orc_obstacle;
 
+/* second analytic family, the commented alternates of the demos (NonObstacleDemo.jl:7-11,15-22 with four
+ * terms; ObstacleDemo.jl:9-11,15-17 with two):  c = 1 + sum_k a_k sin(pi r_k),  r_k = |(x,y) - (x_k,y_k)|,
+ * grad c = sum_k a_k pi cos(pi r_k)/r_k * [(x - x_k), (y - y_k)]                                        */
+#define ORC_RADIAL_MAX 4
+typedef struct { int K; double a[ORC_RADIAL_MAX], x[ORC_RADIAL_MAX], y[ORC_RADIAL_MAX]; } orc_radial;
+
 typedef struct {
-    int kind;              /* 0 = sinprod analytic, 1 = grid tables */
+    int kind;              /* 0 = sinprod analytic, 1 = grid tables, 2 = radial sine sum */
     orc_sinprod sp;
     int N; double ext;     /* grid */
     const double *eval, *grad, *p;
     int arith;             /* grid only: 0 = as written (un-fused), 1 = "fused" flavour (ray_oracle.c) */
+    orc_radial rad;
 } orc_medium;
 
 void   orc_linspace(double a, double b, int n, double *out);
@@ -63,6 +70,7 @@ int    orc_discrete_hamilton(const double X[4], const double *eval, const double
 int    orc_discrete_hamilton_fused(const double X[4], const double *eval, const double *grad,
                                    const double *p, int N, double H[4]);
 void   orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4]);
+void   orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4]);
 
 /* initial boundary phase-space grid, rows for sources [src_begin, src_end) */
 void   orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, double dir_hi,

@@ -55,6 +55,45 @@ class SinProd:
         return [s2 * X[2], s2 * X[3], ((-tau) * g[0]) * speed, ((-tau) * g[1]) * speed], 0
 
 
+class RadialSineSum:
+    """The commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17):
+    c = 1 + sum a_k sin(pi r_k), grad c = sum a_k pi cos(pi r_k)/r_k [(x - x_k), (y - y_k)]."""
+
+    def __init__(self, terms):
+        self.terms = [tuple(t) for t in terms]          # (a_k, x_k, y_k)
+
+    @staticmethod
+    def smooth_alt():    # NonObstacleDemo.jl:7-11
+        return RadialSineSum([(0.2, 0.5, 0.2), (0.4, -0.4, -0.3), (0.2, 0.3, -0.4), (0.3, -0.2, 0.1)])
+
+    @staticmethod
+    def obstacle_alt():  # ObstacleDemo.jl:9-11
+        return RadialSineSum([(0.4, 0.5, 0.2), (0.4, -0.4, -0.3)])
+
+    def c(self, x, y):
+        v = 1.0
+        for a, xk, yk in self.terms:
+            r = sqrt((x - xk) * (x - xk) + (y - yk) * (y - yk))
+            v = v + a * sin(pi * r)
+        return v
+
+    def gradc(self, x, y):
+        g = None
+        for a, xk, yk in self.terms:
+            dx, dy = x - xk, y - yk
+            r = sqrt(dx * dx + dy * dy)
+            f = ((a * pi) * cos(pi * r)) / r
+            g = [f * dx, f * dy] if g is None else [g[0] + f * dx, g[1] + f * dy]
+        return g
+
+    def hamilton(self, X):  # NonObstacle.jl:1-4
+        speed = self.c(X[0], X[1])
+        g = self.gradc(X[0], X[1])
+        tau = X[2] * X[2] + X[3] * X[3]
+        s2 = speed * speed
+        return [s2 * X[2], s2 * X[3], ((-tau) * g[0]) * speed, ((-tau) * g[1]) * speed], 0
+
+
 class Circle:  # ObstacleDemo.jl:20-34
     def __init__(self, r0):
         self.r0 = r0

@@ -123,6 +123,35 @@ class SinProd:
         return cache[id(ctx)]
 
 
+class RadialSineSum:
+    """c = 1 + sum_k a_k sin(pi |x - x_k|), grad c = sum_k a_k pi cos(pi r_k)/r_k (x - x_k): the commented
+    alternate media of the demos (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17).  terms: up to
+    four (a_k, x_k, y_k)."""
+
+    def __init__(self, terms):
+        self.terms = [(float(a), float(x), float(y)) for a, x, y in terms]
+
+    @classmethod
+    def smooth_alt(cls):           # NonObstacleDemo.jl:7-11
+        return cls([(0.2, 0.5, 0.2), (0.4, -0.4, -0.3), (0.2, 0.3, -0.4), (0.3, -0.2, 0.1)])
+
+    @classmethod
+    def obstacle_alt(cls):         # ObstacleDemo.jl:9-11
+        return cls([(0.4, 0.5, 0.2), (0.4, -0.4, -0.3)])
+
+    def __call__(self, x, y):      # waveSpeed(x, y), for filling grids on the host
+        v = 1.0
+        for a, xk, yk in self.terms:
+            v = v + a * math.sin(math.pi * math.sqrt((x - xk) * (x - xk) + (y - yk) * (y - yk)))
+        return v
+
+    def _medium(self, ctx):
+        cache = self.__dict__.setdefault("_handles", {})
+        if id(ctx) not in cache:
+            cache[id(ctx)] = _Medium.radial(ctx, self.terms)
+        return cache[id(ctx)]
+
+
 class Circle:
     """ob = sqrt(x^2+y^2) - r0, normal (x,y)/r (ObstacleDemo.jl:20-34)."""
 
@@ -157,6 +186,16 @@ class _Medium:
     def sinprod(cls, ctx, params):
         h = C.c_void_p()
         _lib.check(ctx._lib.ray_medium_create_sinprod(ctx.handle, *params, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def radial(cls, ctx, terms):
+        h = C.c_void_p()
+        K = len(terms)
+        a = (C.c_double * max(K, 1))(*[t[0] for t in terms])
+        x = (C.c_double * max(K, 1))(*[t[1] for t in terms])
+        y = (C.c_double * max(K, 1))(*[t[2] for t in terms])
+        _lib.check(ctx._lib.ray_medium_create_radial(ctx.handle, K, a, x, y, C.byref(h)))
         return cls(ctx, h)
 
     def close(self):
@@ -212,7 +251,7 @@ def _resolve(c, gradc, ctx):
         raise RayError("pass the medium descriptor itself (or None) as its gradient: closures "
                        "cannot cross the C ABI onto the GPU")
     if not hasattr(c, "_medium"):
-        raise RayError("c must be a SinProd or GridMedium descriptor, not a Python function")
+        raise RayError("c must be a SinProd, RadialSineSum or GridMedium descriptor, not a Python function")
     return c._medium(ctx)
 
 

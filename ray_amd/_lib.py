@@ -52,6 +52,7 @@ SIGNATURES = {
     "ray_medium_update_grid_dev": [_vp, _vp],
     "ray_medium_export_tables": [_vp, _vp, _vp, _vp],
     "ray_medium_create_sinprod": [_vp, _f64, _f64, _f64, _f64, _f64, C.POINTER(_vp)],
+    "ray_medium_create_radial": [_vp, _i32, _vp, _vp, _vp, C.POINTER(_vp)],
     "ray_medium_destroy": [_vp],
     "ray_shoot_to_exit": [_vp, _vp, C.POINTER(Obstacle), C.POINTER(ShootParams), _vp, _i64, _vp, _vp, _vp],
     "ray_shoot_to_exit_dev": [_vp, _vp, C.POINTER(Obstacle), C.POINTER(ShootParams), _vp, _i64, _vp, _vp, _vp],

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
             double sn, cs;
             sincos(theta, &sn, &cs);
             const double c0 = (MED == kGrid) ? speed_grid(a.med.g, lds_nodes(), sx, sy, oob)
+                            : (MED == kRadial) ? speed_radial(a.med.rd, sx, sy)
                                              : speed_sinprod(a.med.sp, sx, sy);
             X[0] = sx; X[1] = sy; X[2] = cs / c0; X[3] = sn / c0;
 #pragma unroll
@@ -576,6 +577,7 @@ struct ray_medium {
     ray_ctx *ctx = nullptr;
     int kind = kSinProd;
     SinProdDev sp{};
+    RadialDev rd{};
     int N = 0;
     double ext = 0;
     double *d_c = nullptr, *d_rec = nullptr, *d_p = nullptr;
@@ -879,6 +881,20 @@ int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, doub
     return RAY_OK;
 }
 
+int ray_medium_create_radial(ray_ctx *ctx, int K, const double *a, const double *xk, const double *yk, ray_medium **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    if (K < 1 || K > kRadialMax || !a || !xk || !yk) return fail(RAY_ERR_INVALID, "radial medium: 1..4 terms (a, x, y)");
+    ray_medium *m = new ray_medium;
+    m->ctx = ctx; m->kind = kRadial;
+    m->rd.K = K;
+    for (int k = 0; k < K; ++k) { m->rd.a[k] = a[k]; m->rd.x[k] = xk[k]; m->rd.y[k] = yk[k]; }
+    *out = m;
+    return RAY_OK;
+}
+
 int ray_medium_destroy(ray_medium *med)
 {
     if (!med) return RAY_OK;
@@ -895,6 +911,7 @@ static MediumDev medium_dev(const ray_medium *m)
 {
     MediumDev d{};
     d.sp = m->sp;
+    d.rd = m->rd;
     if (m->kind == kGrid) {
         d.g.rec = m->d_rec; d.g.hrec = m->d_hrec; d.g.p = m->d_p; d.g.N = m->N;
         d.g.p1 = m->p[0];
@@ -975,11 +992,13 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
         if (med->kind == kGrid) {
             if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 1, lds);
             else RAY_LAUNCH_BY_OB(kGrid, kExact, 1, lds);
-        } else RAY_LAUNCH_BY_OB(kSinProd, kExact, 1, 0);
+        } else if (med->kind == kRadial) RAY_LAUNCH_BY_OB(kRadial, kExact, 1, 0);
+        else RAY_LAUNCH_BY_OB(kSinProd, kExact, 1, 0);
     } else if (med->kind == kGrid) {
         if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 0, lds);
         else RAY_LAUNCH_BY_OB(kGrid, kExact, 0, lds);
-    } else RAY_LAUNCH_BY_OB(kSinProd, kExact, 0, 0);
+    } else if (med->kind == kRadial) RAY_LAUNCH_BY_OB(kRadial, kExact, 0, 0);
+    else RAY_LAUNCH_BY_OB(kSinProd, kExact, 0, 0);
 #undef RAY_LAUNCH_BY_OB
 #undef RAY_LAUNCH_SHOOT
     time_end(ctx, e0, e1);

@@ -33,8 +33,10 @@ struct GridDev {
     double nb;           // RN(-p1*rh): kFused cell index = floor(fma(x, rh, nb))
 };
 struct SinProdDev { double A, wx, wy, gx, gy; };
+constexpr int kRadialMax = 4;
+struct RadialDev { int K; int pad_; double a[kRadialMax], x[kRadialMax], y[kRadialMax]; };
 
-enum MediumKind { kSinProd = 0, kGrid = 1 };
+enum MediumKind { kSinProd = 0, kGrid = 1, kRadial = 2 };
 enum ObstacleKind { kObNone = 0, kObCircle = 1, kObTrefoil = 2 };
 
 // correctly rounded a/b given rb = RN(1/b) (Markstein); see header comment
@@ -439,9 +441,47 @@ __device__ __forceinline__ double speed_sinprod(const SinProdDev &s, double x, d
     return 1 + s.A * sin(s.wx * x) * sin(s.wy * y);
 }
 
+// a1 with the commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), as written:
+//   c      = 1.0 + a1 * sin(pi * r1) + a2 * sin(pi * r2) + ...             r_k = sqrt((x-x_k)^2 + (y-y_k)^2)
+//   grad c = a1 * pi * cos(pi * r1)/r1 * [(x-x1), (y-y1)] + ...
+__device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4], double H[4])
+{
+    constexpr double kPi = 3.141592653589793;
+    double speed = 1.0, g0 = 0, g1 = 0;
+#pragma unroll
+    for (int k = 0; k < kRadialMax; ++k)
+        if (k < rd.K) {
+            const double dx = X[0] - rd.x[k], dy = X[1] - rd.y[k];
+            const double r = __builtin_sqrt(dx * dx + dy * dy);
+            double sn, cs;
+            sincos(kPi * r, &sn, &cs);
+            speed = speed + rd.a[k] * sn;
+            const double f = ((rd.a[k] * kPi) * cs) / r;
+            if (k == 0) { g0 = f * dx; g1 = f * dy; }
+            else { g0 = g0 + f * dx; g1 = g1 + f * dy; }
+        }
+    const double tau = X[2] * X[2] + X[3] * X[3];
+    const double s2 = speed * speed;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = ((-tau) * g0) * speed;
+    H[3] = ((-tau) * g1) * speed;
+}
+__device__ __forceinline__ double speed_radial(const RadialDev &rd, double x, double y)
+{
+    constexpr double kPi = 3.141592653589793;
+    double speed = 1.0;
+    for (int k = 0; k < rd.K; ++k) {
+        const double dx = x - rd.x[k], dy = y - rd.y[k];
+        speed = speed + rd.a[k] * sin(kPi * __builtin_sqrt(dx * dx + dy * dy));
+    }
+    return speed;
+}
+
 struct MediumDev {
     GridDev g;
     SinProdDev sp;
+    RadialDev rd;
 };
 
 template <int MED, int AR, int MODE = kFetch>
@@ -449,6 +489,7 @@ __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const
                                     unsigned long long lm, RecState &rs)
 {
     if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm, rs);
+    else if (MED == kRadial) rhs_radial(m.rd, X, H);
     else rhs_sinprod(m.sp, X, H);
 }
 

@@ -209,6 +209,32 @@ def test_trefoil_bad_parameters(ctx):
                                         4, 8, 1e-2, ctx=ctx)
 
 
+@pytest.mark.parametrize("name", ["smooth", "obstacle"])
+def test_scatter_radial_golden(ctx, name):
+    """the commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17)."""
+    import ray_amd
+    g = golden("scatter_radial_%s_ns8_nd16.npz" % name)
+    med = ray_amd.RadialSineSum(g["terms"])
+    if float(g["r0"]) > 0:
+        m, info = ray_amd.ScatterRelationObstacle(med, None, ray_amd.Circle(float(g["r0"])), None, int(g["ns"]),
+                                                  int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+        assert info["nreflect"].sum() > 0
+    else:
+        m, info = ray_amd.ScatterRelation(med, None, int(g["ns"]), int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
+
+
+def test_scatter_radial_vs_oracle(ctx, orc):
+    import ray_amd
+    ns, nd, dt = 40, 96, 1e-2
+    ref, st, nst, nrf = orc.scatter_relation(orc.SMOOTH_ALT, ns, nd, dt, nthreads=8)
+    m, info = ray_amd.ScatterRelation(ray_amd.RadialSineSum.smooth_alt(), None, ns, nd, dt, ctx=ctx, info=True)
+    assert_rays(m, info, ref, st, nst, nrf)
+    assert np.all(st == orc.ST_EXITED)
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.ScatterRelation(ray_amd.RadialSineSum([(0.1, 0, 0)] * 5), None, 4, 4, dt, ctx=ctx)
+
+
 def test_theta_block_equals_whole(ctx):
     """shooting sources [a,b) must give exactly the rows of the full sweep (multi-GPU sharding)."""
     import ray_amd
