@@ -124,12 +124,29 @@ def main():
     nsteps = torch.empty(num, dtype=torch.int32, device=dev)
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
 
+    trace = os.environ.get("RAY_BENCH_TRACE") == "1"            # progress lines on stderr (rehearsals)
+
+    def say(msg):
+        if trace:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    def allreduce(t, op=None):
+        """RCCL on the device tensor; the gloo rehearsal reduces a host copy (gloo's device path is not what
+        the real run uses)."""
+        op = op or dist.ReduceOp.SUM
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+
     def step():
         rdev.shoot_to_exit_dev(ctx, med, ns_total, ND, DT, m.data_ptr(), num, src_begin=sb, src_end=se,
                                status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr())
         rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, sums.data_ptr())
         if world > 1:
-            dist.all_reduce(sums)          # the one collective per iteration (misfit sums)
+            allreduce(sums)                # the one collective per iteration (misfit sums)
 
     def fence():
         torch.cuda.synchronize()
@@ -138,13 +155,16 @@ def main():
         torch.cuda.synchronize()
 
     # the observation = the data itself from a first pass, perturbed (misfit cost is data-independent)
+    say("medium built")
     step()
     torch.cuda.synchronize()
+    say("first step done")
     obs.copy_(m)
     obs[4 * num:8 * num] *= 1.001
     for _ in range(args.warmup):
         step()
     fence()
+    say("warm-up done")
     ctx.reset_counters()
     ctx.enable_timing(True)
     t0 = time.perf_counter()
@@ -152,14 +172,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    say("timed region done")
     cnt = ctx.counters()
     ctx.enable_timing(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(cnt["ray_steps"]), float(cnt["rays"])], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot)
+        allreduce(el, dist.ReduceOp.MAX)
+        allreduce(tot)
     elapsed = float(el.item())
     ray_steps, rays = float(tot[0].item()), float(tot[1].item())
 
