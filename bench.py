@@ -46,7 +46,14 @@ def cpu_baseline(seconds_target=12.0):
     t0 = time.perf_counter()
     _, _, nst, _ = orc.scatter_relation(tab, NS_PER_GPU, ND, DT, src_begin=0, src_end=S, nthreads=threads)
     el = time.perf_counter() - t0
+    # the same at one thread (SURVEY.md section 8d asks for both), on a sample ~3 s long
+    S1 = max(1, min(S, int(S * 3.0 / seconds_target / threads) + 1))
+    t1 = time.perf_counter()
+    _, _, nst1, _ = orc.scatter_relation(tab, NS_PER_GPU, ND, DT, src_begin=0, src_end=S1, nthreads=1)
+    el1 = time.perf_counter() - t1
     return {"value": float(nst.sum() / el), "unit": "ray-steps/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": float(nst1.sum() / el1), "cores": 1,
+                              "sample": f"sources [0,{S1}): {int(nst1.sum())} ray-steps in {el1:.2f} s"},
             "sample": f"sources [0,{S}) x {ND} directions of the same 2048x2048 / 512^2 / dt=1e-2 "
                       f"workload: {int(nst.sum())} ray-steps in {el:.2f} s (C port of the "
                       "reference's Julia CPU path, -O2 -ffp-contract=off, OpenMP over rays)"}
