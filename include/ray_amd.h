@@ -224,6 +224,13 @@ int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
                     int32_t max_pts, double *path_host, int32_t *npts, int32_t *status,
                     int32_t *nsteps, int32_t *nreflect);
 
+/* NonReflectionPlot (Obstacle.jl:222-274, without the plotting): the fixed-time trace of
+ * ray_trace_fixed_time plus the polyline `res` of every ray -- its start and the position after every
+ * step (Obstacle.jl:256,266).  Layout of path_host / npts as in ray_shoot_paths.                        */
+int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num, int64_t ld,
+                    double dt, int32_t mode, int32_t max_pts, double *path_host, int32_t *npts,
+                    double *X_host, int64_t ldx, int32_t *status, int32_t *nsteps);
+
 /* ---- ray classification (Utility.jl:1-39; ObstacleDemo.jl:48-67; SURVEY.md section 8f NEXT-3) -----------
  * m: (ns*nd, >=8 columns), rows source-major as ScatterRelation(Obstacle) writes them.
  *   ortho[r] = similarity(m[r,1:2], m[r,5:6]) > 0.995 && similarity(m[r,3:4], m[r,7:8]) < -0.995

@@ -306,15 +306,17 @@ def _rk4_k(med, X, dt):  # NonObstacle.jl:161-164,171 ; Obstacle.jl:312-317
     return [X[k] + (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) * dt / 6.0 for k in range(4)], oob
 
 
-def trace_fixed_time(grid, rows, T, timeStep, mode, step_cap=10000000):
+def trace_fixed_time(grid, rows, T, timeStep, mode, step_cap=10000000, paths=None):
     """mode 0 = a9 X-only (NonObstacle.jl:146-157,161,171,177-181,185);
-    mode 1 = a8 (Obstacle.jl:306-326).  Returns list of (X[4], status, nsteps)."""
+    mode 1 = a8 (Obstacle.jl:306-326).  Returns list of (X[4], status, nsteps).  paths (a list) receives
+    the polyline `res` of NonReflectionPlot per ray (Obstacle.jl:256,266): start, then every step."""
     p = grid.p
     cease_r = 1 + 2 * (p[1] - p[0])
     out = []
     for X0, Ti in zip(rows, T):
         X = list(X0)
         t, dt, st, steps = 0, timeStep, 0, 0
+        res = [(X[0], X[1])]
         while t < Ti:
             if steps >= step_cap:
                 st |= ST_STEP_CAP
@@ -329,7 +331,10 @@ def trace_fixed_time(grid, rows, T, timeStep, mode, step_cap=10000000):
             if mode == 0 and sqrt(X[0] * X[0] + X[1] * X[1]) > cease_r:
                 t = t + (Ti - t)
                 st |= ST_CEASED
+            res.append((X[0], X[1]))
         out.append((X, st, steps))
+        if paths is not None:
+            paths.append(res)
     return out
 
 

@@ -346,6 +346,30 @@ def ScatterRelationObstaclePlot(c, gradc, ob, gradob, ns, nd, dt, rayIndex, *, c
     return m, paths
 
 
+def NonReflectionPlot(c, m, ext, dt, *, ctx=None, max_pts=4096, info=False):
+    """Obstacle.jl:222-274 without PyPlot: traces every row of m from m[:,1:4] for the time m[:,9] (the
+    overshooting loop of NonReflectionTrace) and returns the polylines `res` -- start and the position
+    after every step -- ready for `plot(p[:,0], p[:,1])`."""
+    ctx = ctx or default_context()
+    med = c if isinstance(c, GridMedium) else GridMedium(c, ext, ctx)
+    m = np.asfortranarray(m, dtype=np.float64)
+    num = m.shape[0]
+    X = np.zeros((num, 4), order="F")
+    st = np.zeros(num, dtype=np.int32)
+    nst = np.zeros(num, dtype=np.int32)
+    npts = np.zeros(num, dtype=np.int32)
+    path = np.zeros((num, max_pts, 2), dtype=np.float64)
+    _lib.check(ctx._lib.ray_trace_paths(ctx.handle, med.handle, _ptr(m), num, max(num, 1), float(dt),
+                                        TRACE_OVERSHOOT, max_pts, _ptr(path), _ptr(npts), _ptr(X), max(num, 1),
+                                        _ptr(st), _ptr(nst)))
+    if num and npts.max() > max_pts:
+        raise RayError(f"a ray produced {int(npts.max())} points; raise max_pts (= {max_pts})")
+    paths = [path[k, :npts[k]].copy() for k in range(num)]
+    if info:
+        return paths, {"X": X, "status": st, "nsteps": nst, "npts": npts}
+    return paths
+
+
 def _trace(c, m, ext, dt, mode, ctx, info):
     ctx = ctx or default_context()
     if isinstance(c, SinProd):

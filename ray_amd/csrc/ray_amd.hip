@@ -333,12 +333,17 @@ struct TraceArgs {
     int64_t ldx;
     int32_t *status, *nsteps;
     unsigned long long *step_counter;
+    double *path;         // PATH variant: [ray][point][x,y] polylines (NonReflectionPlot's `res`), else null
+    int32_t *npts;
+    int max_pts;
 };
 
 // a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
 // NonObstacle.jl:146-157,161-164,171,177-181,185).  Same wave-converged stepping as k_shoot;
 // the clock is per lane here (every ray has its own T and its own shortened last step).
-template <int AR>
+// PATH = 1 also records `res` of NonReflectionPlot (Obstacle.jl:256,266): the start and the position after
+// every step.
+template <int AR, int PATH = 0>
 __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,6 +361,12 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
     double t = 0, dt = a.dt;
     bool active = valid && t < T;
     RecState rs;
+    int np = 0;
+    auto put = [&](double x, double y) {
+        if (np < a.max_pts) reinterpret_cast<double2 *>(a.path)[r * a.max_pts + np] = make_double2(x, y);
+        ++np;
+    };
+    if (PATH && valid) put(X[0], X[1]);                     // res = X[1:2]            Obstacle.jl:256
     // one back edge, one exit (wave-uniform); live lanes left at the cap get STEP_CAP below
     if (__builtin_amdgcn_ballot_w64(active) != 0 && a.max_steps > 0) do {
         double dtl = 0.0;
@@ -382,11 +393,13 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
                 else out = __builtin_sqrt(s) > a.cease_r;
                 if (out) { t = t + (T - t); st |= kStCeased; }                    // NonObstacle.jl:177-181
             }
+            if (PATH) put(Xn[0], Xn[1]);                    // res = [res X[1:2]]      Obstacle.jl:266
             active = t < T;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) X[k] = Xn[k];
     } while (__builtin_amdgcn_ballot_w64(active) != 0 && it < a.max_steps);
+    if (PATH && valid && a.npts) a.npts[r] = np;
     if (active) st |= kStStepCap;
     if (oob) st |= kStOob;
     if (valid) {
@@ -1187,9 +1200,9 @@ int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
 }
 
 // ---- fixed-time trace -------------------------------------------------------------------------------
-int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
-                             int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
-                             int32_t *status_dev, int32_t *nsteps_dev)
+static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
+                          int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
+                          int32_t *status_dev, int32_t *nsteps_dev, double *path_dev, int32_t *npts_dev, int max_pts)
 {
     int rc = use(ctx);
     if (rc) return rc;
@@ -1209,13 +1222,24 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
     const dim3 tgrid((unsigned)((num + block_threads() - 1) / block_threads())), tblock(block_threads());
-    if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_trace<kFused>, tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
-    else hipLaunchKernelGGL(k_trace<kExact>, tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+    if (path_dev) {
+        a.path = path_dev; a.npts = npts_dev; a.max_pts = max_pts;
+        if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 1>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+        else hipLaunchKernelGGL((k_trace<kExact, 1>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+    } else if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 0>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+    else hipLaunchKernelGGL((k_trace<kExact, 0>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)num;
     ctx->launches += 1;
     return RAY_OK;
+}
+
+int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
+                             int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
+                             int32_t *status_dev, int32_t *nsteps_dev)
+{
+    return trace_dev_impl(ctx, med, m_dev, num, ld, dt, mode, X_dev, ldx, status_dev, nsteps_dev, nullptr, nullptr, 0);
 }
 
 int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num,
@@ -1237,6 +1261,39 @@ int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_ho
                                   ob_.st.as<int32_t>(), ob_.ns.as<int32_t>());
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
+    if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// NonReflectionPlot's data (Obstacle.jl:222-274 without the plotting): the overshoot trace plus polylines
+int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num, int64_t ld,
+                    double dt, int32_t mode, int32_t max_pts, double *path_host, int32_t *npts,
+                    double *X_host, int64_t ldx, int32_t *status, int32_t *nsteps)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (!m_host || !X_host || !path_host || !npts || num < 0 || ld < num || ldx < num || max_pts < 1)
+        return fail(RAY_ERR_INVALID, "bad m / X / path / npts / num / ld / max_pts");
+    if (num == 0) return RAY_OK;
+    const size_t pbytes = sizeof(double) * 2 * (size_t)max_pts * (size_t)num;
+    DevBuf dm, dX, dpath, dnp;
+    RayOutBufs ob_;
+    HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
+    HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
+    HIPCHK(dpath.alloc(pbytes));
+    HIPCHK(dnp.alloc(sizeof(int32_t) * (size_t)num));
+    if ((rc = ob_.alloc(num))) return rc;
+    HIPCHK(hipMemsetAsync(dpath.p, 0, pbytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(dnp.p, 0, sizeof(int32_t) * (size_t)num, ctx->stream));
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
+    if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
+    rc = trace_dev_impl(ctx, med, dm.as<double>(), num, num, dt, mode, dX.as<double>(), num,
+                        ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), dpath.as<double>(), dnp.as<int32_t>(), max_pts);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
+    HIPCHK(hipMemcpyAsync(path_host, dpath.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(npts, dnp.p, sizeof(int32_t) * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;

@@ -64,3 +64,33 @@ def test_paths_grid_exact_bits(ctx, orc):
     assert np.array_equal(m[:, 4:8], np.array([o[0] for o in ref]))
     with pytest.raises(ray_amd.RayError):
         ray_amd.shoot_paths(med, m, 1e-2, ctx=ctx, max_pts=8)
+
+
+def test_nonreflection_plot_exact_bits(ctx, orc):
+    """NonReflectionPlot's polylines (Obstacle.jl:222-274): the overshoot trace, start + every step,
+    bit-identical to the restatement in the exact flavour."""
+    import ray_amd
+    P = _py()
+    from conftest import golden
+    g = golden("grid_n75_ns8_nd16.npz")
+    N = int(g["N"])
+    grid = P.Grid(list(np.asarray(g["c"]).flatten(order="F")), N, float(g["ext"]))
+    rows = [list(r) for r in g["m"][:32, 0:4]]
+    T = [float(t) for t in g["m"][:32, 8]]
+    ref_paths = []
+    ref = P.trace_fixed_time(grid, rows, T, 5e-2, 1, paths=ref_paths)
+    m = np.asfortranarray(g["m"][:32].copy())
+    ctx.set_arith(ray_amd.ARITH_EXACT)
+    try:
+        paths, info = ray_amd.NonReflectionPlot(np.asfortranarray(g["c"]), m, float(g["ext"]), 5e-2, ctx=ctx,
+                                                max_pts=128, info=True)
+    finally:
+        ctx.set_arith(ray_amd.ARITH_FUSED)
+    assert len(paths) == 32
+    for p, rp in zip(paths, ref_paths):
+        assert np.array_equal(p, np.array(rp))
+    assert np.array_equal(info["X"], np.array([o[0] for o in ref]))
+    assert np.array_equal(info["npts"], info["nsteps"] + 1)
+    assert np.array_equal(info["X"], g["X_overshoot"][:32])
+    with pytest.raises(ray_amd.RayError):
+        ray_amd.NonReflectionPlot(np.asfortranarray(g["c"]), m, float(g["ext"]), 5e-2, ctx=ctx, max_pts=4)
