@@ -187,6 +187,11 @@ int ray_frechet_shape(ray_frechet *f, int64_t *n_rows, int64_t *n_cols, int64_t 
 int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, double *data);
 /* the same three arrays where they live in HBM (valid until ray_frechet_destroy) */
 int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data);
+/* Waits for the context's stream, then releases the handle.  Its three CSR arrays are parked on the
+ * context (the largest of each kind) and handed to the next ray_forward_operator that fits in them, and
+ * the operator's intermediates live in grow-only workspaces of the context: a reconstruction loop that
+ * builds M every iteration (NonObstacle.jl:331-333) allocates nothing after the first one.  All of it is
+ * released by ray_ctx_destroy; destroy every handle before its context.                               */
 int ray_frechet_destroy(ray_frechet *f);
 
 /* ---- passes of the reconstruction loop over M (NonObstacle.jl:340-367; SURVEY.md section 8f NEXT-2) ----

@@ -569,8 +569,13 @@ struct ray_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     // grow-only device workspaces reused across calls (the Frechet stencil slab: a reconstruction loop
     // calls ScatterForwardOperator every iteration with the same sizes)
-    void *ws[2] = {nullptr, nullptr};
-    size_t ws_cap[2] = {0, 0};
+    static constexpr int kWs = 12;
+    void *ws[kWs] = {};
+    size_t ws_cap[kWs] = {};
+    // one retired CSR triple (ray_frechet_destroy parks it here, the next ray_forward_operator takes it
+    // back if it is large enough): the loop frees M and builds the next one every iteration
+    void *csr_pool[3] = {};
+    size_t csr_cap[3] = {};
 };
 
 static hipError_t ctx_workspace(ray_ctx *ctx, int k, size_t bytes, void **out)
@@ -610,6 +615,24 @@ struct BorrowedBuf {                           // same accessors as DevBuf, memo
     void *p;
     template <class T> T *as() { return static_cast<T *>(p); }
 };
+struct WsBuf {                                 // DevBuf's interface over workspace slot k of the context
+    ray_ctx *ctx;
+    int k;
+    void *p = nullptr;
+    WsBuf(ray_ctx *c, int slot) : ctx(c), k(slot) {}
+    hipError_t alloc(size_t bytes) { return ctx_workspace(ctx, k, bytes ? bytes : 8, &p); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+// CSR arrays of a ray_frechet: from the context's parked triple when it fits, else fresh
+static hipError_t csr_take(ray_ctx *ctx, int which, size_t bytes, void **out)
+{
+    if (ctx->csr_pool[which] && ctx->csr_cap[which] >= bytes) {
+        *out = ctx->csr_pool[which];
+        ctx->csr_pool[which] = nullptr; ctx->csr_cap[which] = 0;
+        return hipSuccess;
+    }
+    return hipMalloc(out, bytes ? bytes : 8);
+}
 
 static int use(ray_ctx *ctx)
 {
@@ -758,7 +781,8 @@ int ray_ctx_destroy(ray_ctx *ctx)
     delete ctx->init;
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-    for (int k = 0; k < 2; ++k) if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
+    for (int k = 0; k < ray_ctx::kWs; ++k) if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
+    for (int k = 0; k < 3; ++k) if (ctx->csr_pool[k]) (void)hipFree(ctx->csr_pool[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RAY_OK;
@@ -1307,15 +1331,40 @@ struct ray_frechet {
     int64_t *d_indptr = nullptr;        // 4 num + 1
     int32_t *d_indices = nullptr;       // nnz, sorted within a row
     double *d_data = nullptr;           // nnz
+    size_t cap[3] = {0, 0, 0};          // bytes behind the three arrays
 };
+
+// the three CSR arrays of f (sizes known): parked triple of the context or fresh memory
+static hipError_t frechet_alloc(ray_frechet *f, int which, size_t bytes)
+{
+    void *p = nullptr;
+    size_t have = f->ctx->csr_pool[which] && f->ctx->csr_cap[which] >= bytes ? f->ctx->csr_cap[which] : (bytes ? bytes : 8);
+    hipError_t e = csr_take(f->ctx, which, bytes, &p);
+    if (e != hipSuccess) return e;
+    f->cap[which] = have;
+    if (which == 0) f->d_indptr = static_cast<int64_t *>(p);
+    else if (which == 1) f->d_indices = static_cast<int32_t *>(p);
+    else f->d_data = static_cast<double *>(p);
+    return hipSuccess;
+}
 
 int ray_frechet_destroy(ray_frechet *f)
 {
     if (!f) return RAY_OK;
-    if (f->ctx) (void)hipSetDevice(f->ctx->device);
-    if (f->d_indptr) (void)hipFree(f->d_indptr);
-    if (f->d_indices) (void)hipFree(f->d_indices);
-    if (f->d_data) (void)hipFree(f->d_data);
+    void *arr[3] = {f->d_indptr, f->d_indices, f->d_data};
+    if (f->ctx) {
+        (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->stream);             // nothing of this handle is in flight after this
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (!arr[k]) continue;
+        // park the larger of (this array, what is parked); free the other
+        if (f->ctx && f->cap[k] > f->ctx->csr_cap[k]) {
+            if (f->ctx->csr_pool[k]) (void)hipFree(f->ctx->csr_pool[k]);
+            f->ctx->csr_pool[k] = arr[k];
+            f->ctx->csr_cap[k] = f->cap[k];
+        } else (void)hipFree(arr[k]);
+    }
     delete f;
     return RAY_OK;
 }
@@ -1370,7 +1419,8 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     if (slots * 40 * 2 + (size_t)num * 512 > free_b)
         return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the stencil slab does not fit in device memory (sum of T/dt too large); split the rays");
-    DevBuf dm, dX, drho, dbase, dcap, ducnt, duoff, ducols, duvals, drowcnt;
+    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), duoff(ctx, 8),
+          ducols(ctx, 9), duvals(ctx, 10), drowcnt(ctx, 11);
     RayOutBufs ob_;
     void *pkeys = nullptr, *pvals = nullptr;
     HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * sizeof(int64_t), &pkeys));
@@ -1437,10 +1487,10 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
                        dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), drho.as<double>(), duoff.as<int64_t>(), droptol,
                        ducols.as<int32_t>(), duvals.as<double>(), drowcnt.as<int32_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMalloc((void **)&f->d_indptr, sizeof(int64_t) * (size_t)(4 * num + 1)));
+    HIPCHK(frechet_alloc(f, 0, sizeof(int64_t) * (size_t)(4 * num + 1)));
     if ((rc = scan_counts(ctx, drowcnt.as<int32_t>(), 4 * num, f->d_indptr, &f->nnz))) return rc;
-    HIPCHK(hipMalloc((void **)&f->d_indices, sizeof(int32_t) * (size_t)(f->nnz ? f->nnz : 1)));
-    HIPCHK(hipMalloc((void **)&f->d_data, sizeof(double) * (size_t)(f->nnz ? f->nnz : 1)));
+    HIPCHK(frechet_alloc(f, 1, sizeof(int32_t) * (size_t)(f->nnz ? f->nnz : 1)));
+    HIPCHK(frechet_alloc(f, 2, sizeof(double) * (size_t)(f->nnz ? f->nnz : 1)));
     hipLaunchKernelGGL(k_csr_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, ducols.as<int32_t>(), duvals.as<double>(),
                        duoff.as<int64_t>(), f->d_indptr, droptol, f->d_indices, f->d_data);
     HIPCHK(hipGetLastError());
@@ -1471,7 +1521,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     ray_frechet *f = new ray_frechet;
     f->ctx = ctx; f->num = num; f->N = med->N;
     if (num == 0) {
-        if (hipMalloc((void **)&f->d_indptr, sizeof(int64_t)) != hipSuccess || hipMemset(f->d_indptr, 0, sizeof(int64_t)) != hipSuccess) {
+        if (frechet_alloc(f, 0, sizeof(int64_t)) != hipSuccess || hipMemset(f->d_indptr, 0, sizeof(int64_t)) != hipSuccess) {
             ray_frechet_destroy(f);
             return fail(RAY_ERR_HIP, "ray_forward_operator: allocation failed");
         }
@@ -1521,9 +1571,9 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         if (rc) { (void)hipStreamSynchronize(ctx->stream); drop(); return rc; }
         nnz += q->nnz;
     }
-    hipError_t e = hipMalloc((void **)&f->d_indptr, sizeof(int64_t) * (size_t)(4 * num + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->d_indices, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->d_data, sizeof(double) * (size_t)(nnz ? nnz : 1));
+    hipError_t e = frechet_alloc(f, 0, sizeof(int64_t) * (size_t)(4 * num + 1));
+    if (e == hipSuccess) e = frechet_alloc(f, 1, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    if (e == hipSuccess) e = frechet_alloc(f, 2, sizeof(double) * (size_t)(nnz ? nnz : 1));
     int64_t at = 0;
     for (size_t c = 0; e == hipSuccess && c < pieces.size(); ++c) {
         ray_frechet *q = pieces[c];
