@@ -198,3 +198,34 @@ def test_forward_operator_sort_key_widths_agree(ctx, orc, monkeypatch, N, ns, nd
     assert np.array_equal(M1.data, M2.data) and np.array_equal(s1, s2)
     Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
     assert np.max(np.abs(M1.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+
+
+def test_forward_operator_is_the_derivative_at_scale(ctx, orc):
+    """Size-independent property at grids the dense oracle cannot hold (N = 257: 32-bit sort keys; N = 1024,
+    BASELINE config 5's grid: 64-bit keys): (s(c + eps d) - s(c - eps d)) / 2 eps -> M d, with the O(h)
+    defect of the reference's operator (tests/test_oracle.py::test_forward_operator_is_the_derivative)
+    shrinking under refinement."""
+    import ray_amd
+    defect = []
+    for N in (257, 1024):
+        c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+        m, *_ = orc.scatter_relation(orc.SMOOTH_DEMO, 16, 48, 1e-2, nthreads=8)
+        m = np.asfortranarray(m)
+        m[:, 8] *= 0.8                                   # stay inside the disc: no cease branch
+        x = np.linspace(-1.5, 1.5, N)
+        d = np.asfortranarray(np.exp(-((x[:, None] - 0.1) ** 2 + (x[None, :] + 0.2) ** 2) / 0.18))
+        med = ray_amd.GridMedium(c, 1.5, ctx)
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 2e-2, ctx=ctx)
+        assert not info["status"].any()
+        lin = F.matvec(d.reshape(-1, order="F"))
+        nnz = F.tocsr().nnz
+        F.close()
+        eps = 1e-6
+        med.update(np.asfortranarray(c + eps * d))
+        Xp, _ = ray_amd._trace(med, m, 1.5, 2e-2, ray_amd.TRACE_SHORTEN_CEASE, ctx, True)
+        med.update(np.asfortranarray(c - eps * d))
+        Xm, _ = ray_amd._trace(med, m, 1.5, 2e-2, ray_amd.TRACE_SHORTEN_CEASE, ctx, True)
+        fd = ((Xp - Xm) / (2 * eps)).reshape(-1)
+        defect.append(np.linalg.norm(lin - fd) / np.linalg.norm(fd))
+        assert nnz > 4 * m.shape[0] * 50
+    assert defect[0] < 0.02 and defect[1] < 0.6 * defect[0], defect
