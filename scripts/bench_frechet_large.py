@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""ScatterForwardOperator at a size that goes through the chunked assembly: ns x nd rays on an N^2 grid,
+M left on the device (its CSR would be tens of GB on the host).  usage: bench_frechet_large.py [ns nd N dt]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import ray_amd
+    ns, nd, N = (int(v) for v in (sys.argv[1:4] or (512, 512, 513)))
+    dt = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-2
+    ctx = ray_amd.Context(0)
+    sp = ray_amd.SinProd.smooth_demo()
+    p = np.zeros(N)
+    ray_amd._lib.check(ctx._lib.ray_linspace(-1.5, 1.5, N, p.ctypes.data))
+    sx, sy = np.sin(1.5 * np.pi * p), np.sin(1.5 * np.pi * p)
+    c = np.asfortranarray(1 + 0.3 * sx[:, None] * sy[None, :])
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    m = ray_amd.ScatterRelation(med, None, ns, nd, 1e-2, ctx=ctx)
+    for rep in range(2):
+        ctx.reset_counters(); ctx.enable_timing(True)
+        t0 = time.perf_counter()
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, dt, ctx=ctx)
+        t_all = time.perf_counter() - t0
+        cnt = ctx.counters(); ctx.enable_timing(False)
+        rows, cols, nnz = F.shape[0], F.shape[1], F.nnz
+        y = F.matvec(np.ones(cols))
+        F.close()
+        print(json.dumps({"workload": f"ScatterForwardOperator {ns}x{nd} rays, N={N}, dt={dt}", "call": rep,
+                          "rays": int(m.shape[0]), "ray_steps": int(info["nsteps"].sum()), "nnz": int(nnz),
+                          "csr_GB": nnz * 12 / 1e9, "kernel_ms": cnt["kernel_ms"], "launches": cnt["launches"],
+                          "call_s": t_all, "ray_steps_per_s_call": float(info["nsteps"].sum() / t_all),
+                          "bad_status": int((info["status"] & ~16).astype(bool).sum()),
+                          "matvec_finite": bool(np.isfinite(y).all())}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
