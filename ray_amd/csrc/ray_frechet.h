@@ -115,6 +115,33 @@ __device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4]
     jac_from_point(g, X, q, Jm, oob);
 }
 
+// One RK4 stage of the Jacobian equation, column by column so that only four entries of V = Jm * Rin are
+// alive at a time: acc (+)= wa * V, Rout = base + c * V.  Rout may be Rin (column j of Rin is consumed
+// before it is overwritten).  Element for element the same operations as mat4_mul + the two updates.
+template <int MODE>   // 0: acc = V (stage 1); 1: acc += 2 V (stages 2, 3); 2: Rout = base + c * (acc + V) (stage 4)
+__device__ __forceinline__ void rho_stage(const double Jm[16], const double Rin[16], const double base[16],
+                                          double acc[16], double Rout[16], double c)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double t = Jm[i * 4] * Rin[j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) t = __builtin_fma(Jm[i * 4 + k], Rin[k * 4 + j], t);
+            v[i] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * 4 + j;
+            if (MODE == 0) { acc[e] = v[i]; Rout[e] = __builtin_fma(v[i], c, base[e]); }
+            else if (MODE == 1) { acc[e] = __builtin_fma(2.0, v[i], acc[e]); Rout[e] = __builtin_fma(v[i], c, base[e]); }
+            else Rout[e] = __builtin_fma(acc[e] + v[i], c, base[e]);
+        }
+    }
+}
+
 __device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
 {
 #pragma unroll
@@ -317,35 +344,27 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         fin = false;
         if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
-        double H[4], Y[4], accx[4], Jm[16], V[16], R[16], accr[16];
+        double H[4], Y[4], accx[4], Jm[16], R[16], accr[16];
         int o = o0;
         const double hdt = 0.5 * dtl;
         jac_from_point(a.med.g, X, q0, Jm, o);
-        mat4_mul(Jm, rho, V);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = k1[k]; Y[k] = (AR == kFused) ? __builtin_fma(k1[k], hdt, X[k]) : X[k] + k1[k] * hdt; }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { accr[k] = V[k]; R[k] = __builtin_fma(V[k], hdt, rho[k]); }
+        rho_stage<0>(Jm, rho, rho, accr, R, hdt);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
-        mat4_mul(Jm, R, V);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], hdt, X[k]) : X[k] + H[k] * hdt; }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { accr[k] = __builtin_fma(2.0, V[k], accr[k]); R[k] = __builtin_fma(V[k], hdt, rho[k]); }
+        rho_stage<1>(Jm, R, rho, accr, R, hdt);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
-        mat4_mul(Jm, R, V);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], dtl, X[k]) : X[k] + H[k] * dtl; }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { accr[k] = __builtin_fma(2.0, V[k], accr[k]); R[k] = __builtin_fma(V[k], dtl, rho[k]); }
+        rho_stage<1>(Jm, R, rho, accr, R, dtl);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
-        mat4_mul(Jm, R, V);
         const double dt6 = dtl * 0.16666666666666666;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             X[k] = (AR == kFused) ? __builtin_fma(accx[k] + H[k], dt6, X[k]) : X[k] + div6((accx[k] + H[k]) * dtl);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) rho[k] = __builtin_fma(accr[k] + V[k], dt6, rho[k]);
+        rho_stage<2>(Jm, R, rho, accr, rho, dt6);
         ++it;
         wp = 0.0;
         if (active) {
