@@ -215,6 +215,8 @@ def main():
             "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK, "traffic": traffic,
+                         # the same launch against the other roof: recorded HBM bytes / kernel time / 8 TB/s
+                         "hbm_frac": (traffic / kern_s / 8.0e12) if traffic else None,
                          "l2_hit_rate": l2_hit,
                          "kernel_ms": kern_s * 1e3, "ray_steps_per_launch": steps_per_launch,
                          "flop_per_ray_step": F_STEP_GRID,
