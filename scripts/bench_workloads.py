@@ -45,8 +45,8 @@ def main():
     circle = ray_amd.Circle(0.3)
     trefoil = ray_amd.Trefoil.demo()
 
-    def shoot(med, ob, tu):
-        return lambda: rdev.shoot_to_exit_dev(ctx, med, ns, nd, 1e-2, m.data_ptr(), num, ob=ob, time_unit=tu,
+    def shoot(med, ob, tu, dt=1e-2):
+        return lambda: rdev.shoot_to_exit_dev(ctx, med, ns, nd, dt, m.data_ptr(), num, ob=ob, time_unit=tu,
                                               status_ptr=st.data_ptr(), nsteps_ptr=nst.data_ptr(),
                                               nreflect_ptr=nrf.data_ptr())
 
@@ -72,6 +72,8 @@ def main():
 
     run("shoot grid512 smooth", shoot(gsmooth, None, 0), "fused")
     run("shoot grid512 smooth", shoot(gsmooth, None, 0), "exact")
+    # SURVEY.md section 8d's secondary point: dt = h/2 (half a cell per step)
+    run("shoot grid512 smooth dt=h/2", shoot(gsmooth, None, 0, (p[1] - p[0]) / 2), "fused")
     run("shoot analytic smooth (NonObstacleDemo medium)", shoot(smooth, None, 0))
     run("shoot analytic obstacle circle0.3 (ObstacleDemo workload)", shoot(obst, circle, 1))
     run("shoot grid512 obstacle circle0.3", shoot(gobst, circle, 1))
