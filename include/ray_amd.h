@@ -63,6 +63,9 @@ int         ray_ctx_destroy(ray_ctx *ctx);
 /* borrow a caller-owned hipStream_t (pass NULL to return to the context's own stream) */
 int         ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream);
 int         ray_ctx_synchronize(ray_ctx *ctx);
+/* frees the device memory the context keeps between calls (ray_forward_operator's grow-only workspaces
+ * and the parked CSR arrays of the last destroyed ray_frechet); the next call allocates again.        */
+int         ray_ctx_release_workspaces(ray_ctx *ctx);
 /* Arithmetic flavour of the gridded kernels (DiscreteHamilton NonObstacle.jl:30-42 + the RK4
  * combinations NonObstacle.jl:72-76,161-171).  The reference evaluates them under @fastmath, so its
  * own results are defined only up to multiply-add contraction:

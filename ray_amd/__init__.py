@@ -60,6 +60,10 @@ class Context:
     def synchronize(self):
         _lib.check(self._lib.ray_ctx_synchronize(self.handle))
 
+    def release_workspaces(self):
+        """Free what the context keeps between ScatterForwardOperator calls (workspaces, parked CSR arrays)."""
+        _lib.check(self._lib.ray_ctx_release_workspaces(self.handle))
+
     def set_stream(self, hip_stream):
         _lib.check(self._lib.ray_ctx_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ray_ctx_destroy": [_vp],
     "ray_ctx_set_stream": [_vp, _vp],
     "ray_ctx_synchronize": [_vp],
+    "ray_ctx_release_workspaces": [_vp],
     "ray_ctx_set_arith": [_vp, C.c_int],
     "ray_medium_create_grid": [_vp, _vp, C.c_int, _f64, C.POINTER(_vp)],
     "ray_medium_update_grid": [_vp, _vp],

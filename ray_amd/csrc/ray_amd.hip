@@ -805,6 +805,19 @@ int ray_ctx_synchronize(ray_ctx *ctx)
     return RAY_OK;
 }
 
+// gives back what the context keeps between calls (the Frechet workspaces, the parked CSR arrays)
+int ray_ctx_release_workspaces(ray_ctx *ctx)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < ray_ctx::kWs; ++k)
+        if (ctx->ws[k]) { (void)hipFree(ctx->ws[k]); ctx->ws[k] = nullptr; ctx->ws_cap[k] = 0; }
+    for (int k = 0; k < 3; ++k)
+        if (ctx->csr_pool[k]) { (void)hipFree(ctx->csr_pool[k]); ctx->csr_pool[k] = nullptr; ctx->csr_cap[k] = 0; }
+    return RAY_OK;
+}
+
 // ---- media ------------------------------------------------------------------------------------
 static int build_tables(ray_medium *med)
 {

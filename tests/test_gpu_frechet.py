@@ -229,3 +229,25 @@ def test_forward_operator_is_the_derivative_at_scale(ctx, orc):
         defect.append(np.linalg.norm(lin - fd) / np.linalg.norm(fd))
         assert nnz > 4 * m.shape[0] * 50
     assert defect[0] < 0.02 and defect[1] < 0.6 * defect[0], defect
+
+
+def test_workspaces_are_reused_and_released(ctx, orc):
+    """a second identical call reuses the context's workspaces and the closed handle's CSR arrays (same
+    device addresses); release_workspaces gives them back and the next call still works."""
+    import ray_amd
+    c, tab, m = _data(orc, 41, 4, 16, 1)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    F1, X1, *_ = ray_amd.forward_operator_dev(med, m, 1.5, 5e-2, ctx=ctx)
+    a1 = F1.device_arrays()
+    M1 = F1.tocsr()
+    F1.close()
+    F2, X2, *_ = ray_amd.forward_operator_dev(med, m, 1.5, 5e-2, ctx=ctx)
+    a2 = F2.device_arrays()
+    assert tuple(a1) == tuple(a2)
+    M2 = F2.tocsr()
+    F2.close()
+    assert np.array_equal(M1.data, M2.data) and np.array_equal(M1.indices, M2.indices) and np.array_equal(X1, X2)
+    ctx.release_workspaces()
+    F3, X3, *_ = ray_amd.forward_operator_dev(med, m, 1.5, 5e-2, ctx=ctx)
+    assert np.array_equal(F3.tocsr().data, M1.data) and np.array_equal(X3, X1)
+    F3.close()
