@@ -186,3 +186,50 @@ def test_wide_fan_many_runs(ctx, orc, arith):
     st, nst, _ = orc.shoot(tab, ref, 1e-2, nthreads=8)
     info = ray_amd.shoot_states(med, rows, 1e-2, ctx=ctx)
     assert np.array_equal(rows, ref) and np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_media_and_states_vs_oracle(ctx, orc, seed):
+    """Randomised parity: a random smooth wavespeed on a random grid size / extent, rays started anywhere in
+    the disk with random slowness directions, a random step.  Exact flavour: every output bit-identical to the
+    as-written oracle (shooting and both fixed-time traces); fused flavour: bit-identical to the oracle's
+    fused flavour and within 1e-10 of the as-written one; status / step counts identical."""
+    import ray_amd
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(12, 220))
+    ext = float(rng.uniform(1.2, 2.0))
+    dt = float(rng.choice([5e-3, 1e-2, 2e-2, 5e-2]))
+    p = np.linspace(-ext, ext, N)
+    c = np.ones((N, N))
+    for _ in range(4):
+        a, kx, ky, ph = rng.uniform(0.02, 0.08), rng.uniform(0.5, 3), rng.uniform(0.5, 3), rng.uniform(0, 6.28)
+        c += a * np.sin(kx * p[:, None] + ph) * np.cos(ky * p[None, :] - ph)
+    c = np.asfortranarray(c)
+    num = int(rng.integers(65, 700))
+    r, th, ph = 0.95 * np.sqrt(rng.uniform(0, 1, num)), rng.uniform(0, 2 * np.pi, num), rng.uniform(0, 2 * np.pi, num)
+    m0 = np.zeros((num, 9), order="F")
+    m0[:, 0], m0[:, 1] = r * np.cos(th), r * np.sin(th)
+    m0[:, 2], m0[:, 3] = np.cos(ph), np.sin(ph)
+    med = ray_amd.GridMedium(c, ext, ctx)
+    ref_by_arith = {}
+    try:
+        for arith in (0, 1):
+            ctx.set_arith(arith)
+            tab = orc.GridTables(c, ext, arith)
+            ref = np.asfortranarray(m0.copy())
+            st, nst, _ = orc.shoot(tab, ref, dt, nthreads=8)
+            ref_by_arith[arith] = ref
+            m = np.asfortranarray(m0.copy())
+            info = ray_amd.shoot_states(med, m, dt, ctx=ctx)
+            assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
+            assert np.array_equal(m, ref)
+            for mode in (0, 1):
+                X, s2, n2 = orc.trace_fixed_time(tab, ref, 2.5 * dt, mode, nthreads=8)
+                Xg, inf = ray_amd._trace(med, ref, ext, 2.5 * dt, mode, ctx, True)
+                assert np.array_equal(inf["status"], s2) and np.array_equal(inf["nsteps"], n2)
+                assert np.array_equal(Xg, X)
+    finally:
+        ctx.set_arith(ray_amd.ARITH_FUSED)
+    ok = (st & orc.ST_EXITED) != 0
+    d = np.abs(ref_by_arith[1][ok, 4:9] - ref_by_arith[0][ok, 4:9]) / np.maximum(1.0, np.abs(ref_by_arith[0][ok, 4:9]))
+    assert d.max() <= 1e-10

@@ -251,3 +251,34 @@ def test_workspaces_are_reused_and_released(ctx, orc):
     F3, X3, *_ = ray_amd.forward_operator_dev(med, m, 1.5, 5e-2, ctx=ctx)
     assert np.array_equal(F3.tocsr().data, M1.data) and np.array_equal(X3, X1)
     F3.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_forward_operator_random_media(ctx, orc, arith, seed):
+    """Randomised parity of the complete operator: random smooth medium, grid size, extent, step, rays started
+    inside the disk with random directions and random travel times (some long enough to cease)."""
+    import ray_amd
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(14, 44))
+    ext = float(rng.uniform(1.3, 1.8))
+    dt = float(rng.choice([2e-2, 5e-2]))
+    p = np.linspace(-ext, ext, N)
+    c = np.ones((N, N))
+    for _ in range(3):
+        a, kx, ky, ph = rng.uniform(0.03, 0.1), rng.uniform(0.5, 2.5), rng.uniform(0.5, 2.5), rng.uniform(0, 6.28)
+        c += a * np.sin(kx * p[:, None] + ph) * np.cos(ky * p[None, :] - ph)
+    c = np.asfortranarray(c)
+    num = int(rng.integers(20, 90))
+    r, th, ph = 0.8 * np.sqrt(rng.uniform(0, 1, num)), rng.uniform(0, 2 * np.pi, num), rng.uniform(0, 2 * np.pi, num)
+    m = np.zeros((num, 9), order="F")
+    m[:, 0], m[:, 1] = r * np.cos(th), r * np.sin(th)
+    m[:, 2], m[:, 3] = np.cos(ph), np.sin(ph)
+    m[:, 8] = rng.uniform(0.0, 2.2, num)
+    tab = orc.GridTables(c, ext, arith)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+    med = ray_amd.GridMedium(c, ext, ctx)
+    M, s, info = ray_amd.ScatterForwardOperator(med, m, ext, dt, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(info["status"], sto) and np.array_equal(info["nsteps"], nso)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(info["rho"] - rho_o)) <= MTOL * np.max(np.abs(rho_o))
+    assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
