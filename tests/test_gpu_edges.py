@@ -233,3 +233,37 @@ def test_random_media_and_states_vs_oracle(ctx, orc, seed):
     ok = (st & orc.ST_EXITED) != 0
     d = np.abs(ref_by_arith[1][ok, 4:9] - ref_by_arith[0][ok, 4:9]) / np.maximum(1.0, np.abs(ref_by_arith[0][ok, 4:9]))
     assert d.max() <= 1e-10
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_random_obstacle_vs_oracle(ctx, orc, arith, seed):
+    """Randomised a7 parity: random smooth gridded medium, a circle of random radius, rays started between the
+    circle and the boundary in random directions, time in steps: bit-identical, reflections included."""
+    import ray_amd
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(20, 160))
+    ext = float(rng.uniform(1.2, 1.7))
+    dt = float(rng.choice([1e-2, 2e-2]))
+    r0 = float(rng.uniform(0.15, 0.5))
+    p = np.linspace(-ext, ext, N)
+    c = np.ones((N, N))
+    for _ in range(3):
+        a, kx, ky, ph = rng.uniform(0.02, 0.08), rng.uniform(0.5, 3), rng.uniform(0.5, 3), rng.uniform(0, 6.28)
+        c += a * np.sin(kx * p[:, None] + ph) * np.cos(ky * p[None, :] - ph)
+    c = np.asfortranarray(c)
+    num = int(rng.integers(100, 900))
+    r = np.sqrt(rng.uniform((r0 + 0.05) ** 2, 0.95 ** 2, num))
+    th, ph = rng.uniform(0, 2 * np.pi, num), rng.uniform(0, 2 * np.pi, num)
+    m0 = np.zeros((num, 9), order="F")
+    m0[:, 0], m0[:, 1] = r * np.cos(th), r * np.sin(th)
+    m0[:, 2], m0[:, 3] = np.cos(ph), np.sin(ph)
+    tab = orc.GridTables(c, ext, arith)
+    ref = np.asfortranarray(m0.copy())
+    st, nst, nrf = orc.shoot(tab, ref, dt, obstacle_r0=r0, time_unit=1, nthreads=8)
+    med = ray_amd.GridMedium(c, ext, ctx)
+    m = np.asfortranarray(m0.copy())
+    info = ray_amd.shoot_states(med, m, dt, ob=ray_amd.Circle(r0), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
+    assert nrf.sum() > 0
+    assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
+    assert np.array_equal(info["nreflect"], nrf)
+    assert np.array_equal(m, ref)
