@@ -94,3 +94,32 @@ def test_nonreflection_plot_exact_bits(ctx, orc):
     assert np.array_equal(info["X"], g["X_overshoot"][:32])
     with pytest.raises(ray_amd.RayError):
         ray_amd.NonReflectionPlot(np.asfortranarray(g["c"]), m, float(g["ext"]), 5e-2, ctx=ctx, max_pts=4)
+
+
+def test_paths_trefoil_radial(ctx):
+    """polylines around the trefoil obstacle in the radial-sine-sum medium (both commented alternates of
+    ObstacleDemo.jl:8-34 at once): rays with up to several reflections, reflection points on the level set."""
+    import ray_amd
+    P = _py()
+    med, tf = P.RadialSineSum.obstacle_alt(), P.Trefoil(0.4, 0.3, 0.2)
+    ns, nd = 8, 16
+    rows = P.init_states(med, ns, nd, 0.0, np.pi)
+    ref_all = P.shoot(med, rows, 1e-2, obstacle=tf, time_unit=1)
+    pick = [k for k, o in enumerate(ref_all) if o[4] >= 1][:12]
+    assert len(pick) >= 6
+    ref_paths = []
+    ref = P.shoot(med, [rows[k] for k in pick], 1e-2, obstacle=tf, time_unit=1, paths=ref_paths)
+    m, paths = ray_amd.ScatterRelationObstaclePlot(ray_amd.RadialSineSum.obstacle_alt(), None, ray_amd.Trefoil.demo(),
+                                                   None, ns, nd, 1e-2, pick, ctx=ctx)
+    for k, (p, rp, o) in enumerate(zip(paths, ref_paths, ref)):
+        rp = np.array(rp)
+        assert p.shape == rp.shape, (k, p.shape, rp.shape)
+        assert np.max(np.abs(p - rp)) <= 1e-10
+        assert np.max(np.abs(m[pick[k], 4:8] - np.array(o[0]))) <= 1e-10
+    # every reflection point sits on the level set r = R - rho cos 3 theta
+    hits = 0
+    for p, rp in zip(paths, ref_paths):
+        for q in p[1:-1]:
+            if abs(tf.ob(q[0], q[1])) < 1e-14:
+                hits += 1
+    assert hits >= len(pick)
