@@ -403,21 +403,26 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
 // every stage, and all of the first four stages -- run in registers on 16-key chunks: one LDS round
 // trip instead of four.  Keys sit padded by one per 16 (a thread's chunk is 136 bytes from its
 // neighbour's: conflict-free 8-byte reads).
-constexpr int kSortChunk = 16;
-__host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes) { return (size_t)(n2 + n2 / kSortChunk) * key_bytes; }
-__device__ __forceinline__ int spad(int i) { return i + (i >> 4); }
+// chunk = keys a thread sorts in registers = padding period: 16 eight-byte keys, 32 four-byte keys
+__host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes)
+{
+    const int chunk = key_bytes == 4 ? 32 : 16;
+    return (size_t)(n2 + n2 / chunk) * key_bytes;
+}
 
 // Sort keys.  64-bit: node << 40 | emission << 20.  32-bit (chosen by the host when the node index and
 // the emission index fit together: N^2 < 2^(32 - eshift), n2 <= 2^eshift): node << eshift | emission --
 // half the LDS traffic, one-instruction compares, min/max exchanges.
 template <typename K> struct SortKey;
 template <> struct SortKey<uint64_t> {
+    static constexpr int kChunk = 16, kShift = 4;
     static __device__ __forceinline__ uint64_t dead() { return kKeyDead; }
     static __device__ __forceinline__ uint64_t pack(int64_t node, int e, int) { return (uint64_t)node << 40 | (uint64_t)e << 20; }
     static __device__ __forceinline__ uint64_t node(uint64_t k, int) { return k >> 40; }
     static __device__ __forceinline__ uint64_t out(uint64_t k, int, int rank) { return k | (uint64_t)rank; }
 };
 template <> struct SortKey<uint32_t> {
+    static constexpr int kChunk = 32, kShift = 5;
     static __device__ __forceinline__ uint32_t dead() { return 0xffffffffu; }
     static __device__ __forceinline__ uint32_t pack(int64_t node, int e, int es) { return (uint32_t)node << es | (uint32_t)e; }
     static __device__ __forceinline__ uint64_t node(uint32_t k, int es) { return k >> es; }
@@ -427,10 +432,11 @@ template <> struct SortKey<uint32_t> {
     }
 };
 
-// strides min(size/2, 8) .. 1 of bitonic stage `size` on the chunk that starts at key c0
+// strides min(size/2, chunk/2) .. 1 of bitonic stage `size` on the chunk that starts at key c0
 template <typename K>
-__device__ __forceinline__ void sort_chunk_stage(K v[kSortChunk], int c0, int size)
+__device__ __forceinline__ void sort_chunk_stage(K v[SortKey<K>::kChunk], int c0, int size)
 {
+    constexpr int kSortChunk = SortKey<K>::kChunk;
 #pragma unroll
     for (int stride = kSortChunk / 2; stride > 0; stride >>= 1) {
         if (stride < size) {
@@ -453,6 +459,8 @@ __global__ __launch_bounds__(BT) void k_merge_sort(int64_t *__restrict__ keys, c
                                                     const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift)
 {
     typedef SortKey<K> SK;
+    constexpr int kSortChunk = SK::kChunk;
+    auto spad = [](int i) { return i + (i >> SK::kShift); };
     K *sk = reinterpret_cast<K *>(ray_smem);
     __shared__ int s_cnt[BT];
     const int64_t ray = blockIdx.x;
