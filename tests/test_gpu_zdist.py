@@ -18,6 +18,13 @@ def _run(cmd, env, timeout):
     return r.stdout
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_two_rank_reconstruction_equals_one_rank(tmp_path):
     script = os.path.join(ROOT, "examples", "distributed_reconstruction.py")
     args = ["--ns", "48", "--nd", "64", "--N", "45", "--iters", "3", "--rank-thres", "2000"]
@@ -27,7 +34,7 @@ def test_two_rank_reconstruction_equals_one_rank(tmp_path):
     o1, o2 = str(tmp_path / "w1.npy"), str(tmp_path / "w2.npy")
     out1 = _run([sys.executable, script, *args, "--out", o1], env, 200)
     out2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                 "--master-addr", "127.0.0.1", "--master-port", "29547", script, *args, "--out", o2], env, 200)
+                 "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args, "--out", o2], env, 200)
     a, b = np.load(o1), np.load(o2)
     assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(a))
     import json
