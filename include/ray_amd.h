@@ -59,6 +59,9 @@ int         ray_version(void);
 const char *ray_last_error(void);
 int         ray_device_count(int *n);
 int         ray_ctx_create(int device, ray_ctx **out);
+/* also releases the device memory of every medium / ray_frechet handle still alive on the context and
+ * detaches them: their own destroy calls stay valid afterwards (and free the host struct only), every
+ * other call on them reports RAY_ERR_INVALID.                                                         */
 int         ray_ctx_destroy(ray_ctx *ctx);
 /* borrow a caller-owned hipStream_t (pass NULL to return to the context's own stream) */
 int         ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream);
@@ -194,7 +197,7 @@ int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **
  * context (the largest of each kind) and handed to the next ray_forward_operator that fits in them, and
  * the operator's intermediates live in grow-only workspaces of the context: a reconstruction loop that
  * builds M every iteration (NonObstacle.jl:331-333) allocates nothing after the first one.  All of it is
- * released by ray_ctx_destroy; destroy every handle before its context.                               */
+ * released by ray_ctx_destroy (or earlier by ray_ctx_release_workspaces).                              */
 int ray_frechet_destroy(ray_frechet *f);
 
 /* ---- passes of the reconstruction loop over M (NonObstacle.jl:340-367; SURVEY.md section 8f NEXT-2) ----

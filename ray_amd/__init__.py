@@ -203,7 +203,7 @@ class _Medium:
         return cls(ctx, h)
 
     def close(self):
-        if self.handle and self.ctx.handle:
+        if self.handle:                       # safe after the context's own close: the library detached it
             self.ctx._lib.ray_medium_destroy(self.handle)
         self.handle = None
 

@@ -576,7 +576,18 @@ struct ray_ctx {
     // back if it is large enough): the loop frees M and builds the next one every iteration
     void *csr_pool[3] = {};
     size_t csr_cap[3] = {};
+    // handles created on this context and not yet destroyed: ray_ctx_destroy releases their device memory
+    // and detaches them, so that destroying a handle after its context is harmless (only the struct is left)
+    std::vector<struct ray_medium *> media;
+    std::vector<struct ray_frechet *> frechets;
 };
+static void detach_medium(struct ray_medium *m);
+static void detach_frechet(struct ray_frechet *f);
+template <class T> static void forget(std::vector<T *> &v, T *h)
+{
+    for (size_t k = 0; k < v.size(); ++k)
+        if (v[k] == h) { v[k] = v.back(); v.pop_back(); return; }
+}
 
 static hipError_t ctx_workspace(ray_ctx *ctx, int k, size_t bytes, void **out)
 {
@@ -778,6 +789,8 @@ int ray_ctx_destroy(ray_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_timing(ctx);
+    for (ray_medium *m : ctx->media) detach_medium(m);
+    for (ray_frechet *f : ctx->frechets) detach_frechet(f);
     delete ctx->init;
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
@@ -870,6 +883,7 @@ int ray_medium_create_grid(ray_ctx *ctx, const double *c_host, int N, double ext
     }
     rc = ray_medium_update_grid(m, c_host);
     if (rc) { ray_medium_destroy(m); return rc; }
+    ctx->media.push_back(m);
     *out = m;
     return RAY_OK;
 }
@@ -927,6 +941,7 @@ int ray_medium_create_sinprod(ray_ctx *ctx, double A, double wx, double wy, doub
     ray_medium *m = new ray_medium;
     m->ctx = ctx; m->kind = kSinProd;
     m->sp = SinProdDev{A, wx, wy, gx, gy};
+    ctx->media.push_back(m);
     *out = m;
     return RAY_OK;
 }
@@ -941,18 +956,31 @@ int ray_medium_create_radial(ray_ctx *ctx, int K, const double *a, const double 
     m->ctx = ctx; m->kind = kRadial;
     m->rd.K = K;
     for (int k = 0; k < K; ++k) { m->rd.a[k] = a[k]; m->rd.x[k] = xk[k]; m->rd.y[k] = yk[k]; }
+    ctx->media.push_back(m);
     *out = m;
     return RAY_OK;
+}
+
+// device memory of a medium released, handle left without a context (ray_ctx_destroy, ray_medium_destroy)
+static void detach_medium(ray_medium *med)
+{
+    if (med->d_c) (void)hipFree(med->d_c);
+    if (med->d_rec) (void)hipFree(med->d_rec);
+    if (med->d_p) (void)hipFree(med->d_p);
+    if (med->d_hrec) (void)hipFree(med->d_hrec);
+    med->d_c = med->d_rec = med->d_p = med->d_hrec = nullptr;
+    med->ctx = nullptr;
 }
 
 int ray_medium_destroy(ray_medium *med)
 {
     if (!med) return RAY_OK;
-    if (med->ctx) { (void)hipSetDevice(med->ctx->device); (void)hipStreamSynchronize(med->ctx->stream); }
-    if (med->d_c) (void)hipFree(med->d_c);
-    if (med->d_rec) (void)hipFree(med->d_rec);
-    if (med->d_p) (void)hipFree(med->d_p);
-    if (med->d_hrec) (void)hipFree(med->d_hrec);
+    if (med->ctx) {                                   // else: its context went first and took the memory
+        (void)hipSetDevice(med->ctx->device);
+        (void)hipStreamSynchronize(med->ctx->stream);
+        forget(med->ctx->media, med);
+        detach_medium(med);
+    }
     delete med;
     return RAY_OK;
 }
@@ -1361,9 +1389,19 @@ static hipError_t frechet_alloc(ray_frechet *f, int which, size_t bytes)
     return hipSuccess;
 }
 
+static void detach_frechet(ray_frechet *f)
+{
+    if (f->d_indptr) (void)hipFree(f->d_indptr);
+    if (f->d_indices) (void)hipFree(f->d_indices);
+    if (f->d_data) (void)hipFree(f->d_data);
+    f->d_indptr = nullptr; f->d_indices = nullptr; f->d_data = nullptr;
+    f->ctx = nullptr;
+}
+
 int ray_frechet_destroy(ray_frechet *f)
 {
     if (!f) return RAY_OK;
+    if (f->ctx) forget(f->ctx->frechets, f);
     void *arr[3] = {f->d_indptr, f->d_indices, f->d_data};
     if (f->ctx) {
         (void)hipSetDevice(f->ctx->device);
@@ -1533,6 +1571,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
     ray_frechet *f = new ray_frechet;
     f->ctx = ctx; f->num = num; f->N = med->N;
+    ctx->frechets.push_back(f);
     if (num == 0) {
         if (frechet_alloc(f, 0, sizeof(int64_t)) != hipSuccess || hipMemset(f->d_indptr, 0, sizeof(int64_t)) != hipSuccess) {
             ray_frechet_destroy(f);
@@ -1577,6 +1616,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         const int64_t r0 = cuts[c], n = cuts[c + 1] - r0;
         ray_frechet *q = new ray_frechet;
         q->ctx = ctx; q->num = n; q->N = med->N;
+        ctx->frechets.push_back(q);
         pieces.push_back(q);
         rc = forward_operator_impl(ctx, med, m_host + r0, n, ld, dt, droptol, X_host + r0, ldx,
                                    rho_host ? rho_host + 16 * r0 : nullptr, status ? status + r0 : nullptr,

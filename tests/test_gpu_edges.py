@@ -267,3 +267,27 @@ def test_random_obstacle_vs_oracle(ctx, orc, arith, seed):
     assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
     assert np.array_equal(info["nreflect"], nrf)
     assert np.array_equal(m, ref)
+
+
+def test_handles_survive_their_context(orc):
+    """destroying a context first releases the device memory of its media and Frechet handles and detaches
+    them: closing them afterwards is harmless, using them is an error, not a crash."""
+    import ray_amd
+    ctx2 = ray_amd.Context(0)
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 31, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx2)
+    sp = ray_amd.SinProd.smooth_demo()
+    m = ray_amd.ScatterRelation(sp, None, 3, 8, 1e-2, ctx=ctx2)
+    F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 5e-2, ctx=ctx2)
+    assert F.nnz > 0
+    ctx2.close()
+    with pytest.raises(ray_amd.RayError):
+        F.matvec(np.ones(31 * 31))
+    F.close()
+    med.close()
+    sp._handles.clear()
+    # a fresh context works as before
+    ctx3 = ray_amd.Context(0)
+    m3 = ray_amd.ScatterRelation(ray_amd.SinProd.smooth_demo(), None, 3, 8, 1e-2, ctx=ctx3)
+    assert np.array_equal(m3, m)
+    ctx3.close()
