@@ -63,13 +63,15 @@ def recorded_traffic():
     """HBM bytes per launch of the shoot kernel from the newest committed PMC profile
     (profiles/rN/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
     as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process, so
-    this is the recorded figure of the same command, not a live one; None if no profile exists."""
+    this is the RECORDED figure of the same command, not a live one -- the bench line says so in
+    `traffic_source`.  Returns (bytes, l2 hit rate, profile's kernel average in ms, source) or Nones."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
     if not files:
-        return None, None
+        return None, None, None, None
     d = json.load(open(files[-1]))
-    return d.get("traffic_bytes_per_launch"), d.get("l2_hit_rate")
+    src = os.path.relpath(files[-1], ROOT) + " (recorded by rocprofv3 --pmc on an earlier run of this command, not live)"
+    return d.get("traffic_bytes_per_launch"), d.get("l2_hit_rate"), d.get("kernel_avg_ms"), src
 
 
 def main():
@@ -109,7 +111,11 @@ def main():
     from ray_amd import device as rdev
 
     ctx = ray_amd.Context(local)
-    stream = torch.cuda.current_stream()
+    # ONE explicit stream for everything: the library's kernels (borrowed handle), torch's own ops and the
+    # collective (RCCL orders itself against torch's current stream), so that the all-reduce of the misfit sums
+    # is stream-ordered after k_misfit_final and the next shoot after the all-reduce.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_arith(ray_amd.ARITH_FUSED if args.arith == "fused" else ray_amd.ARITH_EXACT)
 
@@ -137,11 +143,14 @@ def main():
         if trace:
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
+    host_reduce = os.environ.get("RAY_BENCH_HOST_REDUCE") == "1"
+
     def allreduce(t, op=None):
-        """RCCL on the device tensor; the gloo rehearsal reduces a host copy (gloo's device path is not what
-        the real run uses)."""
+        """The collective on the DEVICE tensor, ordered on `stream` (RCCL in the real run; gloo's device path in
+        the one-GPU rehearsal).  RAY_BENCH_HOST_REDUCE=1 reduces a host copy instead (round 1's workaround,
+        kept as a knob for comparison)."""
         op = op or dist.ReduceOp.SUM
-        if backend == "nccl":
+        if not host_reduce:
             dist.all_reduce(t, op=op)
         else:
             h = t.cpu()
@@ -183,6 +192,25 @@ def main():
     cnt = ctx.counters()
     ctx.enable_timing(False)
 
+    # the collective really carried every rank's sums: `sums` (reduced in the last timed step) must equal the
+    # rank-ordered sum of the ranks' own misfit sums, recomputed here and gathered
+    if world > 1:
+        own = torch.zeros(2, dtype=torch.float64, device=dev)
+        rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, own.data_ptr())
+        parts = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        stream.synchronize()
+        if backend == "nccl":
+            dparts = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(dparts, own)
+            parts = [t.cpu() for t in dparts]
+        else:
+            dist.all_gather(parts, own.cpu())
+        want = sum(parts[1:], parts[0].clone())
+        got = sums.cpu()
+        if not torch.allclose(got, want, rtol=1e-12, atol=0):
+            raise SystemExit(f"rank {rank}: all-reduced misfit sums {got.tolist()} != sum over ranks {want.tolist()}")
+        say("reduced sums verified against the ranks' own")
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(cnt["ray_steps"]), float(cnt["rays"])], dtype=torch.float64, device=dev)
     if world > 1:
@@ -199,7 +227,7 @@ def main():
         kern_s = cnt["kernel_ms"] * 1e-3 / max(cnt["launches"], 1)
         steps_per_launch = cnt["ray_steps"] / max(cnt["launches"], 1)
         achieved = F_STEP_GRID * steps_per_launch / kern_s / 1e12
-        traffic, l2_hit = recorded_traffic()
+        traffic, l2_hit, prof_ms, traffic_src = recorded_traffic()
         out = {
             "metric": "fp64 RK4 ray-steps/sec", "value": ray_steps / elapsed, "unit": "ray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,10 +243,12 @@ def main():
             "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK, "traffic": traffic,
+                         "traffic_source": traffic_src, "profile_kernel_ms": prof_ms,
                          # the same launch against the other roof: recorded HBM bytes / kernel time / 8 TB/s
                          "hbm_frac": (traffic / kern_s / 8.0e12) if traffic else None,
                          "l2_hit_rate": l2_hit,
-                         "kernel_ms": kern_s * 1e3, "ray_steps_per_launch": steps_per_launch,
+                         "kernel_ms": kern_s * 1e3, "kernel_ms_source": "HIP events around every launch of the timed region, on the launch stream (live)",
+                         "ray_steps_per_launch": steps_per_launch,
                          "flop_per_ray_step": F_STEP_GRID,
                          "kernel_ray_steps_per_s": steps_per_launch / kern_s},
         }

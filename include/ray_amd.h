@@ -63,8 +63,15 @@ int         ray_ctx_create(int device, ray_ctx **out);
  * detaches them: their own destroy calls stay valid afterwards (and free the host struct only), every
  * other call on them reports RAY_ERR_INVALID.                                                         */
 int         ray_ctx_destroy(ray_ctx *ctx);
-/* borrow a caller-owned hipStream_t (pass NULL to return to the context's own stream) */
-int         ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream);
+/* The stream the *_dev entry points enqueue on (and the host-pointer ones stage through).
+ *   RAY_STREAM_OWN       the context's own hipStreamNonBlocking stream (the default); hip_stream is ignored
+ *   RAY_STREAM_BORROWED  the caller's hipStream_t exactly as given: NULL is the legacy default (null)
+ *                        stream, so work the caller orders on that stream (torch's default stream, an RCCL
+ *                        collective issued on it) is ordered with the library's kernels
+ * Waits for the stream being left before switching.                                                    */
+#define RAY_STREAM_OWN      0
+#define RAY_STREAM_BORROWED 1
+int         ray_ctx_set_stream(ray_ctx *ctx, int mode, void *hip_stream);
 int         ray_ctx_synchronize(ray_ctx *ctx);
 /* frees the device memory the context keeps between calls (ray_forward_operator's grow-only workspaces
  * and the parked CSR arrays of the last destroyed ray_frechet); the next call allocates again.        */
@@ -267,6 +274,18 @@ int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64
 int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num,
                    int64_t ld, double *out_dev, uint8_t *mask_dev, double perc_thresh,
                    double *mismatch_dev);
+
+/* Allocation-free variant of ray_misfit_dev.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate -- code under HIP graph capture, tight serving loops that call the misfit every iteration,
+ * harnesses that forbid hipMalloc.  Same kernels and bit-identical results; the scratch (2 x 1024 partial sums,
+ * 16 KB) is a file-scope __device__ array of the library, one copy per GPU, resolved once per device at
+ * ray_ctx_create.  Calls no hipMalloc / hipFree / event creation.  Limit: num <= RAY_MISFIT_STATIC_MAX_RAYS
+ * (RAY_ERR_UNSUPPORTED beyond).  Every call on a GPU shares that GPU's scratch: calls that overlap on one GPU
+ * (two streams, two contexts on one device) race; calls on one stream are ordered and need no clearing.       */
+#define RAY_MISFIT_STATIC_MAX_RAYS ((int64_t)1 << 28)
+int ray_misfit_static_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num,
+                          int64_t ld, double *out_dev, uint8_t *mask_dev, double perc_thresh,
+                          double *mismatch_dev);
 
 /* ---- counters (replaces the reference's tic/toq table, NonObstacle.jl:332-334) ------------- */
 typedef struct {

@@ -3,6 +3,7 @@
 Run from the repo root:  python oracle/gen_golden.py            (all fixtures)
                          python oracle/gen_golden.py trefoil    (only the trefoil one, added later)
                          python oracle/gen_golden.py radial     (only the radial-sine-sum ones, added later)
+                         python oracle/gen_golden.py trefoil_grid   (grid + trefoil "identity" flavour, round 2)
 The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
 path to the Python reading of the reference; the reference itself ships no vectors
 ("parity unpinned" by the reference).
@@ -39,6 +40,22 @@ def trefoil():
              **pack(rows, P.shoot(so, rows, dt, obstacle=tf, time_unit=1)))
 
 
+def trefoil_grid():
+    # G1f: a7 loop over a GRIDDED medium around the trefoil, "identity" flavour of its cos/sin 3 theta
+    #      (x/r, y/r + triple-angle identities: no transcendental anywhere on this path, so the C oracle and
+    #      the HIP kernels must reproduce it bit for bit, events included)
+    ns, nd, dt, N, ext = 8, 16, 1e-2, 33, 1.5
+    so = P.SinProd.obstacle_demo()
+    p = P.linspace(-ext, ext, N)
+    c = [so.c(p[i], p[j]) for j in range(N) for i in range(N)]
+    g = P.Grid(c, N, ext)
+    rows = P.init_states(g, ns, nd, 0.0, pi)
+    tf = P.Trefoil(0.4, 0.3, 0.2, trig="identity")
+    np.savez(os.path.join(OUT, "grid_trefoil_identity_n33_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt, N=N, ext=ext,
+             c=np.array(c).reshape(N, N, order="F"), trefoil=np.array([tf.R, tf.rho, tf.rho_n]),
+             **pack(rows, P.shoot(g, rows, dt, obstacle=tf, time_unit=1)))
+
+
 def radial():
     # G1e: the commented alternate media (NonObstacleDemo.jl:7-11,15-22 four terms, ScatterRelation;
     #      ObstacleDemo.jl:9-11,15-17 two terms with the shipped circle, ScatterRelationObstacle)
@@ -57,7 +74,10 @@ def main():
         return trefoil()
     if sys.argv[1:] == ["radial"]:
         return radial()
+    if sys.argv[1:] == ["trefoil_grid"]:
+        return trefoil_grid()
     trefoil()
+    trefoil_grid()
     radial()
     ns, nd, dt = 8, 16, 1e-2
 

@@ -22,17 +22,33 @@ class SinProd(C.Structure):
 
 
 class Obstacle(C.Structure):
-    _fields_ = [("kind", C.c_int), ("r0", C.c_double), ("rho_ob", C.c_double), ("rho_n", C.c_double)]
+    _fields_ = [("kind", C.c_int), ("r0", C.c_double), ("rho_ob", C.c_double), ("rho_n", C.c_double),
+                ("trig", C.c_int)]
 
 
 def _obstacle(ob):
-    """None, a circle radius, or ("trefoil", R, rho, rho_n)."""
+    """None, a circle radius, or ("trefoil", R, rho, rho_n[, trig]) with trig 0 = libm atan2/cos/sin as the
+    reference writes them (default), 1 = the triple-angle identities on x/r, y/r the HIP kernels evaluate."""
     if ob is None:
-        return Obstacle(0, 0.0, 0.0, 0.0)
+        return Obstacle(0, 0.0, 0.0, 0.0, 0)
     if isinstance(ob, tuple):
         assert ob[0] == "trefoil"
-        return Obstacle(2, float(ob[1]), float(ob[2]), float(ob[3]))
-    return Obstacle(1, float(ob), 0.0, 0.0)
+        return Obstacle(2, float(ob[1]), float(ob[2]), float(ob[3]), int(ob[4]) if len(ob) > 4 else 0)
+    return Obstacle(1, float(ob), 0.0, 0.0, 0)
+
+
+def ob_val(ob, x, y):
+    f = lib().orc_ob_val
+    f.restype = C.c_double
+    o = _obstacle(ob)
+    return f(C.byref(o), C.c_double(x), C.c_double(y))
+
+
+def ob_normal(ob, x, y):
+    n = (C.c_double * 2)()
+    o = _obstacle(ob)
+    lib().orc_ob_normal(C.byref(o), C.c_double(x), C.c_double(y), n)
+    return n[0], n[1]
 
 
 class Radial(C.Structure):

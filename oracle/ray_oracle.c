@@ -331,12 +331,23 @@ static double norm2(double a, double b) { return sqrt(a * a + b * b); }
 
 /* obstacle level set and normal (ObstacleDemo.jl:20-34): the shipped circle, and the commented
  * trefoil alternate  r - (0.4 - rho cos(3 theta))  (:24)  with
- * n = [x, y]/r - 3 rho sin(3 theta)/r * [-y, x]/r  (:31, a rho of its own), n/norm(n) (:33) */
+ * n = [x, y]/r - 3 rho sin(3 theta)/r * [-y, x]/r  (:31, a rho of its own), n/norm(n) (:33).
+ * theta = atan2(y, x) enters only through cos(3 theta) and sin(3 theta).  Two flavours (ob->trig):
+ *   0  as written: atan2, cos, sin of the host libm (results are defined up to that libm);
+ *   1  "identity": cos(theta) = x/r, sin(theta) = y/r and the triple-angle identities
+ *      cos 3t = c (4 c^2 - 3), sin 3t = s (3 - 4 s^2) -- only +,-,*,/,sqrt, every one a single IEEE
+ *      rounding, so the result is the same bits on any conforming machine.  This is what the HIP
+ *      kernels evaluate (ray_amd.hip ob_val / ob_normal); atan2(0, 0) = 0 -> cos(theta) = 1 at r = 0. */
 static double ob_val(const orc_obstacle *ob, double x, double y)
 {
     if (ob->kind == 2) {
-        double theta = atan2(y, x);
         double r = norm2(x, y);
+        if (ob->trig == 1) {
+            double c = r > 0 ? x / r : 1.0;
+            double cos3 = c * (4 * (c * c) - 3);
+            return r - (ob->r0 - ob->rho_ob * cos3);
+        }
+        double theta = atan2(y, x);
         return r - (ob->r0 - ob->rho_ob * cos(3 * theta));
     }
     return norm2(x, y) - ob->r0;
@@ -346,8 +357,10 @@ static void ob_normal(const orc_obstacle *ob, double x, double y, double n[2])
     double r = norm2(x, y);
     double nx = x / r, ny = y / r;
     if (ob->kind == 2) {
-        double theta = atan2(y, x);
-        double s = ((3 * ob->rho_n) * sin(3 * theta)) / r;      /* 3 * rho * sin(3 * theta)/r, left to right */
+        double sin3;
+        if (ob->trig == 1) sin3 = ny * (3 - 4 * (ny * ny));
+        else sin3 = sin(3 * atan2(y, x));
+        double s = ((3 * ob->rho_n) * sin3) / r;                /* 3 * rho * sin(3 * theta)/r, left to right */
         nx = nx - (s * (-y)) / r;
         ny = ny - (s * x) / r;
     }
@@ -355,6 +368,9 @@ static void ob_normal(const orc_obstacle *ob, double x, double y, double n[2])
     n[0] = nx / nn;
     n[1] = ny / nn;
 }
+/* exported for the CPU test that bounds the identity flavour against the libm one */
+double orc_ob_val(const orc_obstacle *ob, double x, double y) { return ob_val(ob, x, y); }
+void orc_ob_normal(const orc_obstacle *ob, double x, double y, double n[2]) { ob_normal(ob, x, y, n); }
 
 /* one classical RK4 step in the a6/a7 form: k = H*dt, X + k1/2, ... /6.0
  * (NonObstacle.jl:72-76; Obstacle.jl:34-38) */

@@ -45,7 +45,13 @@ typedef struct { double A, wx, wy, gx, gy; } orc_sinprod;
 /* obstacle family: kind 0 none, 1 circle r - r0 (ObstacleDemo.jl:20-34 as shipped),
  * 2 trefoil r - (r0 - rho_ob cos 3 theta) with the normal of ObstacleDemo.jl:31, which carries a rho of
  * its own (the commented alternate, :23-24 rho = 0.3 and :30-31 rho = 0.2: the "cavity")       */
-typedef struct { int kind; double r0; double rho_ob, rho_n; } orc_obstacle;
+typedef struct {
+    int kind; double r0; double rho_ob, rho_n;
+    int trig;              /* trefoil only: 0 = atan2/cos/sin of libm as written, 1 = x/r, y/r and the
+                              triple-angle identities (what the HIP kernels evaluate; ray_oracle.c) */
+} orc_obstacle;
+double orc_ob_val(const orc_obstacle *ob, double x, double y);
+void   orc_ob_normal(const orc_obstacle *ob, double x, double y, double n[2]);
 
 /* second analytic family, the commented alternates of the demos (NonObstacleDemo.jl:7-11,15-22 with four
  * terms; ObstacleDemo.jl:9-11,15-17 with two):  c = 1 + sum_k a_k sin(pi r_k),  r_k = |(x,y) - (x_k,y_k)|,

@@ -109,18 +109,29 @@ class Circle:  # ObstacleDemo.jl:20-34
 
 
 class Trefoil:  # the commented alternate of ObstacleDemo.jl:20-34
-    def __init__(self, R=0.4, rho=0.3, rho_n=0.2):
-        self.R, self.rho, self.rho_n = R, rho, rho_n
+    """trig = "libm": atan2 / cos / sin as the reference writes them; trig = "identity": cos(theta) = x/r,
+    sin(theta) = y/r and cos 3t = c (4 c^2 - 3), sin 3t = s (3 - 4 s^2) -- the evaluation the HIP kernels use
+    (only +,-,*,/,sqrt: the same bits on every IEEE machine)."""
+
+    def __init__(self, R=0.4, rho=0.3, rho_n=0.2, trig="libm"):
+        self.R, self.rho, self.rho_n, self.trig = R, rho, rho_n, trig
 
     def ob(self, x, y):          # :21-24  r - (0.4 - rho * cos(3 * theta))
-        theta = atan2(y, x)
         r = sqrt(x * x + y * y)
+        if self.trig == "identity":
+            c = x / r if r > 0 else 1.0
+            return r - (self.R - self.rho * (c * (4 * (c * c) - 3)))
+        theta = atan2(y, x)
         return r - (self.R - self.rho * cos(3 * theta))
 
     def normal(self, x, y):      # :28-33  n = [x, y]/r - 3 * rho * sin(3 * theta)/r * [-y, x]/r; n/norm(n)
-        theta = atan2(y, x)
         r = sqrt(x * x + y * y)
-        s = ((3 * self.rho_n) * sin(3 * theta)) / r
+        if self.trig == "identity":
+            sn = y / r
+            sin3 = sn * (3 - 4 * (sn * sn))
+        else:
+            sin3 = sin(3 * atan2(y, x))
+        s = ((3 * self.rho_n) * sin3) / r
         n = [x / r - (s * (-y)) / r, y / r - (s * x) / r]
         nn = sqrt(n[0] * n[0] + n[1] * n[1])
         return [n[0] / nn, n[1] / nn]

@@ -65,7 +65,13 @@ class Context:
         _lib.check(self._lib.ray_ctx_release_workspaces(self.handle))
 
     def set_stream(self, hip_stream):
-        _lib.check(self._lib.ray_ctx_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+        """Borrow the caller's hipStream_t (an integer handle, e.g. torch.cuda.current_stream().cuda_stream);
+        0 / None is the legacy default stream itself -- torch's default stream -- not the context's own."""
+        _lib.check(self._lib.ray_ctx_set_stream(self.handle, _lib.STREAM_BORROWED, C.c_void_p(hip_stream or 0)))
+
+    def use_own_stream(self):
+        """Back to the context's own non-blocking stream."""
+        _lib.check(self._lib.ray_ctx_set_stream(self.handle, _lib.STREAM_OWN, None))
 
     def set_arith(self, arith):
         """ARITH_EXACT (un-fused, bit-identical to the as-written CPU restatement) or

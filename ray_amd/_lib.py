@@ -12,6 +12,7 @@ OB_NONE, OB_CIRCLE, OB_TREFOIL = 0, 1, 2
 TIME_SECONDS, TIME_STEPS = 0, 1
 TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT = 0, 1
 ARITH_EXACT, ARITH_FUSED = 0, 1
+STREAM_OWN, STREAM_BORROWED = 0, 1
 
 
 class RayError(RuntimeError):
@@ -44,7 +45,7 @@ SIGNATURES = {
     "ray_device_count": [C.POINTER(C.c_int)],
     "ray_ctx_create": [C.c_int, C.POINTER(_vp)],
     "ray_ctx_destroy": [_vp],
-    "ray_ctx_set_stream": [_vp, _vp],
+    "ray_ctx_set_stream": [_vp, C.c_int, _vp],
     "ray_ctx_synchronize": [_vp],
     "ray_ctx_release_workspaces": [_vp],
     "ray_ctx_set_arith": [_vp, C.c_int],
@@ -80,6 +81,7 @@ SIGNATURES = {
     "ray_classify_dev": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "ray_misfit": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_misfit_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
+    "ray_misfit_static_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_ctx_enable_timing": [_vp, C.c_int],
     "ray_get_counters": [_vp, C.POINTER(Counters)],
     "ray_reset_counters": [_vp],

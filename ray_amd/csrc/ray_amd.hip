@@ -537,10 +537,18 @@ __global__ __launch_bounds__(256) void k_misfit_final(const double *__restrict__
     if (threadIdx.x == 0) { out[0] = sm; out[1] = stg; }
 }
 
+// Scratch of ray_misfit_static_dev (include/ray_amd.h): the 2 x kMisfitBlocks partial sums in a file-scope
+// device array instead of a hipMalloc'ed buffer.  Every GPU holds its own copy at its own address; the
+// host never uses the array's name as a pointer -- g_static_partial[dev] is resolved once per device with
+// hipGetSymbolAddress (ray_ctx_create) and handed to the kernels as an argument.
+static __device__ __align__(256) double g_misfit_scratch[2 * kMisfitBlocks];
+
 // =============================================================================================
 // host side
 // =============================================================================================
 static thread_local std::string g_err;
+constexpr int kMaxDevices = 64;
+static double *g_static_partial[kMaxDevices] = {};      // per device: address of g_misfit_scratch there
 
 static int fail(int code, const std::string &msg)
 {
@@ -771,8 +779,15 @@ int ray_ctx_create(int device, ray_ctx **out)
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_steps, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(c->d_steps, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_steps, 0, sizeof(unsigned long long), c->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_partial, sizeof(double) * 2 * kMisfitBlocks);
+    // this device's copy of the static scratch (once per device, with the device current)
+    if (e == hipSuccess && device < kMaxDevices && !g_static_partial[device]) {
+        double *ptr = nullptr;
+        e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_misfit_scratch));
+        if (e == hipSuccess) g_static_partial[device] = ptr;
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("ray_ctx_create: ") + hipGetErrorString(e);
         ray_ctx_destroy(c);
@@ -801,12 +816,15 @@ int ray_ctx_destroy(ray_ctx *ctx)
     return RAY_OK;
 }
 
-int ray_ctx_set_stream(ray_ctx *ctx, void *hip_stream)
+int ray_ctx_set_stream(ray_ctx *ctx, int mode, void *hip_stream)
 {
     int rc = use(ctx);
     if (rc) return rc;
+    if (mode != RAY_STREAM_OWN && mode != RAY_STREAM_BORROWED) return fail(RAY_ERR_INVALID, "bad stream mode");
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    drain_timing(ctx);                              // its events were recorded on the stream being left
+    // BORROWED: the caller's handle exactly as given -- NULL is the legacy default (null) stream
+    ctx->stream = mode == RAY_STREAM_BORROWED ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return RAY_OK;
 }
 
@@ -1573,7 +1591,9 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     f->ctx = ctx; f->num = num; f->N = med->N;
     ctx->frechets.push_back(f);
     if (num == 0) {
-        if (frechet_alloc(f, 0, sizeof(int64_t)) != hipSuccess || hipMemset(f->d_indptr, 0, sizeof(int64_t)) != hipSuccess) {
+        if (frechet_alloc(f, 0, sizeof(int64_t)) != hipSuccess ||
+            hipMemsetAsync(f->d_indptr, 0, sizeof(int64_t), ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
             ray_frechet_destroy(f);
             return fail(RAY_ERR_HIP, "ray_forward_operator: allocation failed");
         }
@@ -1873,18 +1893,40 @@ int ray_debug_stats(unsigned long long out[12])
 #endif
 
 // ---- misfit ---------------------------------------------------------------------------------------
+static int misfit_launch(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
+                         double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev, double *partial)
+{
+    if (!m_dev || !obs_dev || !out_dev || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad misfit arguments");
+    if (mismatch_dev && (reinterpret_cast<uintptr_t>(mismatch_dev) & 15)) return fail(RAY_ERR_INVALID, "mismatch must be 16-byte aligned");
+    // every one of the kMisfitBlocks blocks writes both of its partials (zeros when it has no rays), so the
+    // scratch needs no clearing between calls
+    hipLaunchKernelGGL(k_misfit_partial, dim3(kMisfitBlocks), dim3(256), 0, ctx->stream, m_dev, obs_dev, num, ld,
+                       perc_thresh, mask_dev, mismatch_dev, partial);
+    hipLaunchKernelGGL(k_misfit_final, dim3(1), dim3(256), 0, ctx->stream, partial, out_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
 int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
                    double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev)
 {
     int rc = use(ctx);
     if (rc) return rc;
-    if (!m_dev || !obs_dev || !out_dev || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad misfit arguments");
-    if (mismatch_dev && (reinterpret_cast<uintptr_t>(mismatch_dev) & 15)) return fail(RAY_ERR_INVALID, "mismatch must be 16-byte aligned");
-    hipLaunchKernelGGL(k_misfit_partial, dim3(kMisfitBlocks), dim3(256), 0, ctx->stream, m_dev, obs_dev, num, ld,
-                       perc_thresh, mask_dev, mismatch_dev, ctx->d_partial);
-    hipLaunchKernelGGL(k_misfit_final, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, out_dev);
-    HIPCHK(hipGetLastError());
-    return RAY_OK;
+    return misfit_launch(ctx, m_dev, obs_dev, num, ld, out_dev, mask_dev, perc_thresh, mismatch_dev, ctx->d_partial);
+}
+
+// The allocation-free variant: same kernels, partial sums in this device's copy of g_misfit_scratch.
+// Calls nothing that allocates (no hipMalloc / hipFree, no event creation).
+int ray_misfit_static_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int64_t num, int64_t ld,
+                          double *out_dev, uint8_t *mask_dev, double perc_thresh, double *mismatch_dev)
+{
+    int rc = use(ctx);
+    if (rc) return rc;
+    if (num > RAY_MISFIT_STATIC_MAX_RAYS)
+        return fail(RAY_ERR_UNSUPPORTED, "ray_misfit_static_dev: num exceeds RAY_MISFIT_STATIC_MAX_RAYS (2^28 rays per call)");
+    double *scratch = ctx->device < kMaxDevices ? g_static_partial[ctx->device] : nullptr;
+    if (!scratch) return fail(RAY_ERR_HIP, "ray_misfit_static_dev: the static scratch of this device was not resolved");
+    return misfit_launch(ctx, m_dev, obs_dev, num, ld, out_dev, mask_dev, perc_thresh, mismatch_dev, scratch);
 }
 
 int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64_t num, int64_t ld,
@@ -1937,7 +1979,8 @@ int ray_get_counters(ray_ctx *ctx, ray_counters *out)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drain_timing(ctx);
     unsigned long long s = 0;
-    HIPCHK(hipMemcpy(&s, ctx->d_steps, sizeof(s), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(&s, ctx->d_steps, sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     out->rays = ctx->rays;
     out->ray_steps = s;
     out->launches = ctx->launches;
@@ -1951,7 +1994,7 @@ int ray_reset_counters(ray_ctx *ctx)
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     drain_timing(ctx);
-    HIPCHK(hipMemset(ctx->d_steps, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(ctx->d_steps, 0, sizeof(unsigned long long), ctx->stream));   // ordered before the next launch
     ctx->rays = ctx->launches = 0;
     ctx->kernel_ms = 0;
     return RAY_OK;

@@ -291,3 +291,35 @@ def test_handles_survive_their_context(orc):
     m3 = ray_amd.ScatterRelation(ray_amd.SinProd.smooth_demo(), None, 3, 8, 1e-2, ctx=ctx3)
     assert np.array_equal(m3, m)
     ctx3.close()
+
+
+def test_borrowed_default_stream_orders_with_the_caller(ctx, orc):
+    """ray_ctx_set_stream(RAY_STREAM_BORROWED, NULL) borrows the legacy default stream itself (round 1 turned NULL
+    into the context's own non-blocking stream, which nothing of the caller's was ordered with).  Enqueue a torch
+    op on the default stream, then ray_misfit_dev, then read the result from torch WITHOUT a device-wide sync:
+    stream order alone must make the value right.  Same on an explicit non-default stream."""
+    import torch
+    from ray_amd import device as rdev
+    num = 1 << 20
+    want = None
+    for use_side in (False, True):
+        s = torch.cuda.Stream() if use_side else torch.cuda.default_stream()
+        with torch.cuda.stream(s):
+            ctx.set_stream(s.cuda_stream)                       # 0 for the default stream
+            m = torch.zeros(9 * num, dtype=torch.float64, device="cuda")
+            obs = torch.zeros(9 * num, dtype=torch.float64, device="cuda")
+            out = torch.zeros(2, dtype=torch.float64, device="cuda")
+            for rep in range(3):
+                # a long-ish torch producer right before the library call: if the library ran on another
+                # stream it would read the zeros (or a half-written buffer)
+                for _ in range(20):
+                    m.add_(0.0)
+                m.fill_(float(rep + 1))
+                obs.fill_(0.5)
+                rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, out.data_ptr())
+                got = out.clone()                               # torch consumer, stream-ordered after the library
+                got_h = got.cpu()                               # (a blocking copy on the same stream)
+                d = rep + 1 - 0.5
+                assert got_h[0].item() == pytest.approx(4 * num * d * d, rel=1e-12)
+                assert got_h[1].item() == pytest.approx(4 * num * (rep + 1) ** 2, rel=1e-12)
+    ctx.use_own_stream()

@@ -48,15 +48,22 @@ def assert_rays(m, info, ref_m, ref_st, ref_ns, ref_nr=None, exact=False):
 
 
 def assert_rays_up_to_marginal_events(m, info, ref_m, ref_st, ref_ns, ref_nr, max_frac):
-    """Trefoil obstacle: its level set and normal go through cos / sin of 3 atan2(y, x) -- libm in the oracle,
-    triple-angle identities on x/r, y/r in the kernel (ray_amd.hip ob_val): last bits differ, as between two libms.  The reference's re-arming test `ob(X) > 0` (Obstacle.jl:28-30)
-    is evaluated ON the boundary right after a reflection (X = R with |ob(R)| <= 1e-15), so for a ray that
-    meets the obstacle again within the next step the sign of a rounding error decides whether it
-    reflects or passes: such rays are not defined by the reference beyond its own libm.  Everything else
-    must agree: identical events and values within RTOL; the marginal rays are few and all reflected."""
+    """ANALYTIC medium + trefoil only.  The kernels and the oracle's "identity" flavour evaluate the trefoil's level
+    set and normal with the same IEEE operations (x/r, y/r, triple-angle identities), but the analytic medium's
+    right-hand side goes through sin/cos: device library against host libm, 1-2 ulp apart, so the trajectories
+    differ by ~1e-13.  The reference's re-arming test `ob(X) > 0` (Obstacle.jl:28-30) is evaluated ON the
+    boundary right after a reflection (X = R with |ob(R)| <= 1e-15), and `ob(X) <= 0` (:69) decides a grazing
+    contact: for a ray whose |ob| at such a test is below that trajectory difference, the sign -- reflect or
+    pass -- is not defined by the reference beyond its own libm.  Those rays are listed; everything else must
+    agree: identical events and values within RTOL.  (On gridded media there is no transcendental and the
+    bar is max_frac = 0: test_grid_trefoil_vs_oracle.)"""
     bad = (info["status"] != ref_st) | (info["nsteps"] != ref_ns) | (info["nreflect"] != ref_nr)
+    if bad.any():
+        print("rays with marginal events (row: oracle nreflect/nsteps -> device nreflect/nsteps):",
+              ", ".join("%d: %d/%d -> %d/%d" % (r, ref_nr[r], ref_ns[r], info["nreflect"][r], info["nsteps"][r])
+                        for r in np.flatnonzero(bad)))
     assert bad.mean() <= max_frac, "%d of %d rays classify differently" % (bad.sum(), bad.size)
-    assert np.all((ref_nr[bad] >= 1) & (info["nreflect"][bad] >= 1))
+    assert np.all((ref_nr[bad] >= 1) | (info["nreflect"][bad] >= 1))
     ok = ~bad
     assert rel_err(m[ok, 0:8], ref_m[ok, 0:8]) <= RTOL
     assert np.max(np.abs(m[ok, 8] - ref_m[ok, 8]) / np.maximum(1e-300, np.abs(ref_m[ok, 8]))) <= RTOL
@@ -175,31 +182,47 @@ def test_scatter_trefoil_golden(ctx):
 
 
 def test_scatter_trefoil_vs_oracle(ctx, orc):
-    """ObstacleDemo.jl's sweep (50 x 300, dt = 1e-2, t in steps) around the trefoil: identical events and
-    values within RTOL except for the marginal rays described in assert_rays_up_to_marginal_events
-    (measured: 14 of 15000, all with 1-4 reflections; the others agree to 6e-14)."""
+    """BASELINE config 3's cavity: ObstacleDemo.jl's sweep (50 x 300, dt = 1e-2, t in steps) around the trefoil
+    in the analytic medium, against the oracle's identity flavour (the kernels' own evaluation of the level set).
+    What is left is device-vs-host sin/cos in the medium: see assert_rays_up_to_marginal_events."""
     import ray_amd
     ns, nd, dt = 50, 300, 1e-2
-    tf = ("trefoil", 0.4, 0.3, 0.2)
+    tf = ("trefoil", 0.4, 0.3, 0.2, 1)
     ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=tf, time_unit=1, nthreads=8)
     m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ray_amd.Trefoil.demo(), None,
                                               ns, nd, dt, ctx=ctx, info=True)
     assert nrf.sum() > 1000 and nrf.max() >= 2
-    assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 2e-3)
+    assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 1e-3)
 
 
-def test_grid_trefoil_vs_oracle(ctx, orc, arith):
-    """a7 loop with the trefoil over a gridded medium, from explicit states."""
+def test_grid_trefoil_identity_golden(ctx, arith):
+    """a7 loop over a gridded medium around the trefoil against the committed fixture of the Python restatement
+    (identity flavour): no transcendental on this path -> bit-exact in the exact flavour, events identical."""
     import ray_amd
-    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, 129, 1.5)
+    g = golden("grid_trefoil_identity_n33_ns8_nd16.npz")
+    med = ray_amd.GridMedium(g["c"], float(g["ext"]), ctx)
+    m2 = np.asfortranarray(g["m"].copy())
+    m2[:, 4:] = 0
+    info = ray_amd.shoot_states(med, m2, float(g["dt"]), ob=ray_amd.Trefoil(*g["trefoil"]), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
+    assert g["nreflect"].max() >= 2
+    assert_rays(m2, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=(arith == 0))
+
+
+@pytest.mark.parametrize("N,ns,nd", [(129, 16, 256), (45, 50, 300)])
+def test_grid_trefoil_vs_oracle(ctx, orc, arith, N, ns, nd):
+    """a7 loop with the trefoil (the "cavity" of BASELINE config 3) over a gridded medium, from explicit states:
+    event classification identical and states BIT-exact for every ray, flavour by flavour (the oracle's
+    identity flavour restates the kernels' evaluation of cos/sin 3 theta operation for operation)."""
+    import ray_amd
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, N, 1.5)
     tab = orc.GridTables(c, 1.5, arith)
     med = ray_amd.GridMedium(c, 1.5, ctx)
-    ref, st, nst, nrf = orc.scatter_relation(tab, 16, 256, 1e-2, obstacle_r0=("trefoil", 0.4, 0.3, 0.2), time_unit=1, nthreads=8)
+    ref, st, nst, nrf = orc.scatter_relation(tab, ns, nd, 1e-2, obstacle_r0=("trefoil", 0.4, 0.3, 0.2, 1), time_unit=1, nthreads=8)
     m2 = np.asfortranarray(ref.copy())
     m2[:, 4:] = 0
     info = ray_amd.shoot_states(med, m2, 1e-2, ob=ray_amd.Trefoil.demo(), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
-    assert nrf.sum() > 100
-    assert_rays_up_to_marginal_events(m2, info, ref, st, nst, nrf, 3e-3)
+    assert nrf.sum() > 100 and nrf.max() >= 2
+    assert_rays(m2, info, ref, st, nst, nrf, exact=True)
 
 
 def test_trefoil_bad_parameters(ctx):
@@ -373,11 +396,10 @@ def test_full_size_properties(ctx, orc, arith):
     assert np.max(np.abs(back[ok, 4:6] - m[ok, 0:2])) < 5e-3
     assert np.max(np.abs(back[ok, 8] - m[ok, 8])) < 5e-3
     assert np.all(inf2["status"] & ray_amd.ST_EXITED)
-    # sub-sample against the oracle, bit-exact from the same states
-    idx = np.arange(0, ns * nd, 4099)
-    sub = np.asfortranarray(m[idx].copy())
-    ref = np.asfortranarray(sub.copy())
+    # EVERY ray against the oracle, bit-exact from the same states (4 194 304 rays, ~4 s of CPU on 16 threads)
+    ref = np.asfortranarray(m.copy())
+    ref[:, 4:] = 0
     tab = orc.GridTables(c, 1.5, arith)
     st, nst, _ = orc.shoot(tab, ref, dt, nthreads=16)
-    assert np.array_equal(ref, sub)
-    assert np.array_equal(info["nsteps"][idx], nst) and np.array_equal(info["status"][idx], st)
+    assert np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
+    assert np.array_equal(ref, m)

@@ -1,0 +1,50 @@
+"""ray_misfit_static_dev -- the allocation-free entry point (include/ray_amd.h) -- through the C ABI against
+ray_misfit_dev, bit for bit, on two calls in a row, the second with a smaller input (the static scratch keeps
+the first call's contents).  Collected last (test_zz_*) so that a failure here hides no other test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lib, ctx, fn, m, obs, num, ld, thresh):
+    import torch
+    out = torch.full((2,), -1.0, dtype=torch.float64, device="cuda")
+    mask = torch.full((max(num, 1),), 7, dtype=torch.uint8, device="cuda")
+    mism = torch.full((4 * max(num, 1),), -2.0, dtype=torch.float64, device="cuda")
+    rc = fn(ctx.handle, C.c_void_p(m.data_ptr()), C.c_void_p(obs.data_ptr()), num, ld, C.c_void_p(out.data_ptr()),
+            C.c_void_p(mask.data_ptr()), thresh, C.c_void_p(mism.data_ptr()))
+    assert rc == 0, lib.ray_last_error()
+    ctx.synchronize()
+    return out.cpu().numpy(), mask.cpu().numpy()[:num], mism.cpu().numpy()[:4 * num]
+
+
+def test_static_misfit_matches_misfit_dev_twice(ctx, orc):
+    import torch
+    from ray_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+    ld = 300001
+    host_m = np.asfortranarray(rng.standard_normal((ld, 9)))
+    host_o = np.asfortranarray(host_m + 0.15 * rng.standard_normal((ld, 9)) * rng.random((ld, 1)))
+    m = torch.from_numpy(host_m.T.copy()).cuda().reshape(-1)            # column-major (ld, 9) flattened
+    obs = torch.from_numpy(host_o.T.copy()).cuda().reshape(-1)
+    for num in (300001, 4097, 0):                                       # big, then smaller, then empty
+        want = _run(lib, ctx, lib.ray_misfit_dev, m, obs, num, ld, 0.2)
+        got = _run(lib, ctx, lib.ray_misfit_static_dev, m, obs, num, ld, 0.2)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        # and against the oracle (the existing entry point's own bar)
+        mism, out, mask = orc.misfit(np.asfortranarray(host_m[:num]), np.asfortranarray(host_o[:num]), 0.2)
+        assert np.array_equal(got[2], mism) and np.array_equal(got[1], mask)
+        assert np.allclose(got[0], out, rtol=1e-12, atol=0)
+
+
+def test_static_misfit_rejects_oversize(ctx):
+    from ray_amd import _lib
+    lib = _lib.load()
+    big = (1 << 28) + 1
+    rc = lib.ray_misfit_static_dev(ctx.handle, C.c_void_p(8), C.c_void_p(8), big, big, C.c_void_p(8), None, 0.2, None)
+    assert rc == -4 and b"RAY_MISFIT_STATIC_MAX_RAYS" in lib.ray_last_error()
