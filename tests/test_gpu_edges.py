@@ -295,31 +295,30 @@ def test_handles_survive_their_context(orc):
 
 def test_borrowed_default_stream_orders_with_the_caller(ctx, orc):
     """ray_ctx_set_stream(RAY_STREAM_BORROWED, NULL) borrows the legacy default stream itself (round 1 turned NULL
-    into the context's own non-blocking stream, which nothing of the caller's was ordered with).  Enqueue a torch
-    op on the default stream, then ray_misfit_dev, then read the result from torch WITHOUT a device-wide sync:
-    stream order alone must make the value right.  Same on an explicit non-default stream."""
-    import torch
+    into the context's own non-blocking stream, which nothing of the caller's was ordered with).  The caller
+    enqueues a producer (an async upload of m) on its stream, then ray_misfit_dev, then an async download of the
+    result on the same stream and waits for THAT STREAM only: stream order alone must make the value right.
+    Checked on the default stream (handle 0) and on a non-blocking stream of the caller's."""
+    import hiprt
     from ray_amd import device as rdev
-    num = 1 << 20
-    want = None
-    for use_side in (False, True):
-        s = torch.cuda.Stream() if use_side else torch.cuda.default_stream()
-        with torch.cuda.stream(s):
-            ctx.set_stream(s.cuda_stream)                       # 0 for the default stream
-            m = torch.zeros(9 * num, dtype=torch.float64, device="cuda")
-            obs = torch.zeros(9 * num, dtype=torch.float64, device="cuda")
-            out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    num = 1 << 21
+    side = hiprt.stream_create(nonblocking=True)
+    m_d, obs_d, out_d = hiprt.DevBuf(9 * num * 8), hiprt.DevBuf(9 * num * 8), hiprt.DevBuf(16)
+    obs_d.fill_bytes_async(0, 0)
+    hiprt.hip().hipDeviceSynchronize()
+    try:
+        for stream in (0, side, 0, side):
+            ctx.set_stream(stream)
             for rep in range(3):
-                # a long-ish torch producer right before the library call: if the library ran on another
-                # stream it would read the zeros (or a half-written buffer)
-                for _ in range(20):
-                    m.add_(0.0)
-                m.fill_(float(rep + 1))
-                obs.fill_(0.5)
-                rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, out.data_ptr())
-                got = out.clone()                               # torch consumer, stream-ordered after the library
-                got_h = got.cpu()                               # (a blocking copy on the same stream)
-                d = rep + 1 - 0.5
-                assert got_h[0].item() == pytest.approx(4 * num * d * d, rel=1e-12)
-                assert got_h[1].item() == pytest.approx(4 * num * (rep + 1) ** 2, rel=1e-12)
-    ctx.use_own_stream()
+                val = float(rep + 1) * (1.0 if stream == 0 else 0.5)
+                host = np.full(9 * num, val)
+                got = np.full(2, -1.0)
+                m_d.upload_async(host, stream)                  # producer: 151 MB over PCIe, still in flight when
+                rdev.misfit_dev(ctx, m_d.ptr.value, obs_d.ptr.value, num, num, out_d.ptr.value)   # ... this is enqueued
+                out_d.download_async(got, stream)               # consumer on the same stream
+                hiprt.stream_sync(stream)
+                assert got[0] == pytest.approx(4 * num * val * val, rel=1e-12), (stream, rep)
+                assert got[1] == pytest.approx(4 * num * val * val, rel=1e-12), (stream, rep)
+    finally:
+        ctx.use_own_stream()
+        hiprt.stream_destroy(side)

@@ -195,9 +195,12 @@ def test_scatter_trefoil_vs_oracle(ctx, orc):
     assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 1e-3)
 
 
-def test_grid_trefoil_identity_golden(ctx, arith):
+def test_grid_trefoil_identity_golden(ctx, orc, arith):
     """a7 loop over a gridded medium around the trefoil against the committed fixture of the Python restatement
-    (identity flavour): no transcendental on this path -> bit-exact in the exact flavour, events identical."""
+    (identity flavour): no transcendental on this path -> bit-exact in the exact flavour, events identical.
+    The fused flavour is compared, bit for bit, with the C oracle's fused flavour from the fixture's states (its
+    rounding differs from the as-written fixture's, and a reflection decided ON the boundary -- Obstacle.jl:28-30,69
+    -- may then fall the other way: such rays are counted and must all be reflected ones)."""
     import ray_amd
     g = golden("grid_trefoil_identity_n33_ns8_nd16.npz")
     med = ray_amd.GridMedium(g["c"], float(g["ext"]), ctx)
@@ -205,7 +208,16 @@ def test_grid_trefoil_identity_golden(ctx, arith):
     m2[:, 4:] = 0
     info = ray_amd.shoot_states(med, m2, float(g["dt"]), ob=ray_amd.Trefoil(*g["trefoil"]), time_unit=ray_amd.TIME_STEPS, ctx=ctx)
     assert g["nreflect"].max() >= 2
-    assert_rays(m2, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=(arith == 0))
+    if arith == 0:
+        assert_rays(m2, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
+        return
+    tab = orc.GridTables(g["c"], float(g["ext"]), 1)
+    ref = np.asfortranarray(g["m"].copy())
+    st, nst, nrf = orc.shoot(tab, ref, float(g["dt"]), obstacle_r0=("trefoil",) + tuple(g["trefoil"]) + (1,), time_unit=1)
+    assert_rays(m2, info, ref, st, nst, nrf, exact=True)
+    marginal = (nst != g["nsteps"]) | (nrf != g["nreflect"])
+    assert marginal.sum() <= 2 and np.all(g["nreflect"][marginal] >= 1)
+    assert rel_err(ref[~marginal], g["m"][~marginal]) <= RTOL
 
 
 @pytest.mark.parametrize("N,ns,nd", [(129, 16, 256), (45, 50, 300)])
