@@ -10,27 +10,25 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(lib, ctx, fn, m, obs, num, ld, thresh):
-    import torch
-    out = torch.full((2,), -1.0, dtype=torch.float64, device="cuda")
-    mask = torch.full((max(num, 1),), 7, dtype=torch.uint8, device="cuda")
-    mism = torch.full((4 * max(num, 1),), -2.0, dtype=torch.float64, device="cuda")
-    rc = fn(ctx.handle, C.c_void_p(m.data_ptr()), C.c_void_p(obs.data_ptr()), num, ld, C.c_void_p(out.data_ptr()),
-            C.c_void_p(mask.data_ptr()), thresh, C.c_void_p(mism.data_ptr()))
+    import hiprt
+    out = hiprt.DevBuf.from_numpy(np.full(2, -1.0))
+    mask = hiprt.DevBuf.from_numpy(np.full(max(num, 1), 7, dtype=np.uint8))
+    mism = hiprt.DevBuf.from_numpy(np.full(4 * max(num, 1), -2.0))
+    rc = fn(ctx.handle, m.ptr, obs.ptr, num, ld, out.ptr, mask.ptr, thresh, mism.ptr)
     assert rc == 0, lib.ray_last_error()
     ctx.synchronize()
-    return out.cpu().numpy(), mask.cpu().numpy()[:num], mism.cpu().numpy()[:4 * num]
+    return out.to_numpy(np.float64, 2), mask.to_numpy(np.uint8, max(num, 1))[:num], mism.to_numpy(np.float64, 4 * max(num, 1))[:4 * num]
 
 
 def test_static_misfit_matches_misfit_dev_twice(ctx, orc):
-    import torch
+    import hiprt
     from ray_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(99)
     ld = 300001
     host_m = np.asfortranarray(rng.standard_normal((ld, 9)))
     host_o = np.asfortranarray(host_m + 0.15 * rng.standard_normal((ld, 9)) * rng.random((ld, 1)))
-    m = torch.from_numpy(host_m.T.copy()).cuda().reshape(-1)            # column-major (ld, 9) flattened
-    obs = torch.from_numpy(host_o.T.copy()).cuda().reshape(-1)
+    m, obs = hiprt.DevBuf.from_numpy(host_m), hiprt.DevBuf.from_numpy(host_o)     # column-major (ld, 9)
     for num in (300001, 4097, 0):                                       # big, then smaller, then empty
         want = _run(lib, ctx, lib.ray_misfit_dev, m, obs, num, ld, 0.2)
         got = _run(lib, ctx, lib.ray_misfit_static_dev, m, obs, num, ld, 0.2)
