@@ -100,6 +100,13 @@ def main():
     backend = os.environ.get("RAY_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # RAY_BENCH_FORCE_PG=1: build the process group (and run the collective) even with one rank -- exercises the
+    # RCCL code path of the N > 1 run on a one-GPU box
+    force_pg = os.environ.get("RAY_BENCH_FORCE_PG") == "1" and world == 1
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend, device_id=dev if backend == "nccl" else None, rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -138,17 +145,23 @@ def main():
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
 
     trace = os.environ.get("RAY_BENCH_TRACE") == "1"            # progress lines on stderr (rehearsals)
+    if trace:                                                   # and the Python stacks if nothing has finished by then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("RAY_BENCH_TRACE_DUMP_S", "45")), exit=False, file=sys.stderr)
 
     def say(msg):
         if trace:
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-    host_reduce = os.environ.get("RAY_BENCH_HOST_REDUCE") == "1"
+    # RCCL (the real run): the collective on the DEVICE tensor, ordered on `stream`.  The gloo rehearsal (two ranks
+    # time-slicing one GPU) reduces a host copy: ProcessGroupGloo's own device-tensor all_reduce blocks both ranks
+    # for good on its third call there -- with the stream ordering fixed and with or without HIP timing events
+    # (gpurun_out/r2/bench_2r*.err) -- and is not a path the product uses.
+    # RAY_BENCH_HOST_REDUCE=0 / 1 overrides.
+    host_reduce = os.environ.get("RAY_BENCH_HOST_REDUCE", "1" if backend == "gloo" else "0") == "1"
 
     def allreduce(t, op=None):
-        """The collective on the DEVICE tensor, ordered on `stream` (RCCL in the real run; gloo's device path in
-        the one-GPU rehearsal).  RAY_BENCH_HOST_REDUCE=1 reduces a host copy instead (round 1's workaround,
-        kept as a knob for comparison)."""
+        """One all-reduce of a small device tensor (see host_reduce above)."""
         op = op or dist.ReduceOp.SUM
         if not host_reduce:
             dist.all_reduce(t, op=op)
@@ -161,12 +174,12 @@ def main():
         rdev.shoot_to_exit_dev(ctx, med, ns_total, ND, DT, m.data_ptr(), num, src_begin=sb, src_end=se,
                                status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr())
         rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, sums.data_ptr())
-        if world > 1:
+        if world > 1 or force_pg:
             allreduce(sums)                # the one collective per iteration (misfit sums)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,10 +195,12 @@ def main():
     fence()
     say("warm-up done")
     ctx.reset_counters()
-    ctx.enable_timing(True)
+    notiming = os.environ.get("RAY_BENCH_NOTIMING") == "1"      # rehearsal knob: no HIP events around the launches
+    ctx.enable_timing(not notiming)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         step()
+        say(f"timed step {k} enqueued")
     fence()
     elapsed = time.perf_counter() - t0
     say("timed region done")
@@ -194,7 +209,7 @@ def main():
 
     # the collective really carried every rank's sums: `sums` (reduced in the last timed step) must equal the
     # rank-ordered sum of the ranks' own misfit sums, recomputed here and gathered
-    if world > 1:
+    if world > 1 or force_pg:
         own = torch.zeros(2, dtype=torch.float64, device=dev)
         rdev.misfit_dev(ctx, m.data_ptr(), obs.data_ptr(), num, num, own.data_ptr())
         parts = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
@@ -213,7 +228,7 @@ def main():
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(cnt["ray_steps"]), float(cnt["rays"])], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_pg:
         allreduce(el, dist.ReduceOp.MAX)
         allreduce(tot)
     elapsed = float(el.item())
@@ -255,7 +270,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 
