@@ -275,6 +275,42 @@ int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int
                    int64_t ld, double *out_dev, uint8_t *mask_dev, double perc_thresh,
                    double *mismatch_dev);
 
+/* ---- node-wide fan-out: ONE host process drives every GPU of the node -----------------------------------------
+ * Replaces what the reference's callers get from addprocs(3) (NonObstacleDemo.jl:1, ObstacleDemo.jl:1),
+ * `@sync @parallel` (NonObstacle.jl:59; Obstacle.jl:16), the per-pid remotecall_wait of ScatterForwardOperator
+ * (NonObstacle.jl:236-240) and the serial misfit sum on the master (NonObstacle.jl:336,372): a single call uses
+ * every worker.  A ray_group holds one ray_ctx per listed device; a call launches every member's theta-block
+ * (contiguous sources, sizes differ by at most one) at once and lands each slab in the caller's column-major m;
+ * nothing is exchanged between GPUs except ONE ncclAllReduce(sum, f64) of {sum mismatch^2, sum target^2} per
+ * ray_group_misfit (RCCL: xGMI on the box).  `devices` may name ONE device n times (rehearsal on a one-GPU box;
+ * RCCL refuses two ranks on a device): such a group folds the members' sums with a kernel on that device instead.
+ * Host-pointer entry points, synchronous like the single-context ones.                                        */
+typedef struct ray_group        ray_group;
+typedef struct ray_group_medium ray_group_medium;     /* one replica of the medium per member */
+int ray_group_create(const int *devices, int n, ray_group **out);
+int ray_group_destroy(ray_group *g);                  /* also releases its media (their destroy stays valid) */
+int ray_group_size(const ray_group *g, int *n, int *uses_rccl);
+int ray_group_set_arith(ray_group *g, int arith);
+int ray_group_medium_create_grid(ray_group *g, const double *c_host, int N, double ext, ray_group_medium **out);
+int ray_group_medium_create_sinprod(ray_group *g, double A, double wx, double wy, double gx, double gy,
+                                    ray_group_medium **out);
+int ray_group_medium_update_grid(ray_group_medium *med, const double *c_host);
+int ray_group_medium_destroy(ray_group_medium *med);
+/* ScatterRelation / ScatterRelationObstacle (NonObstacle.jl:54-99; Obstacle.jl:11-97) for sources
+ * [prm->src_begin, prm->src_end) split over the members; arguments as ray_shoot_to_exit.  m_host may be NULL:
+ * the slabs then stay on the devices only (forward-only sweeps that want the misfit alone).                  */
+int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *med, const ray_obstacle *ob,
+                            const ray_shoot_params *prm, double *m_host, int64_t ld,
+                            int32_t *status, int32_t *nsteps, int32_t *nreflect);
+/* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit laid them out; columns 5..8 are
+ * uploaded once, sharded like m, and stay resident                                                            */
+int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld);
+/* misfit of the resident slabs of the last shoot against the resident observation; out / mask / mismatch as
+ * ray_misfit (mask, mismatch may be NULL); sums to 1e-12 of the single-context ones (order of the all-reduce)  */
+int ray_group_misfit(ray_group *g, double out[2], uint8_t *mask, double perc_thresh, double *mismatch);
+/* (ray_group_get_counters, below: rays, ray-steps, launches summed over the members; kernel_ms = the slowest
+ * member's, as they run concurrently)                                                                        */
+
 /* Allocation-free variant of ray_misfit_dev.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate -- code under HIP graph capture, tight serving loops that call the misfit every iteration,
  * harnesses that forbid hipMalloc.  Same kernels and bit-identical results; the scratch (2 x 1024 partial sums,
@@ -297,6 +333,7 @@ typedef struct {
 int ray_ctx_enable_timing(ray_ctx *ctx, int on);   /* record HIP events around each launch */
 int ray_get_counters(ray_ctx *ctx, ray_counters *out);   /* synchronizes the stream */
 int ray_reset_counters(ray_ctx *ctx);
+int ray_group_get_counters(ray_group *g, ray_counters *out);
 
 #ifdef __cplusplus
 }

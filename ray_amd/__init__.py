@@ -256,6 +256,98 @@ class GridMedium(_Medium):
         return self
 
 
+class Group:
+    """All GPUs of the node behind one caller (ray_group): what the reference's callers get from addprocs(3) +
+    @parallel + remotecall_wait (NonObstacleDemo.jl:1; NonObstacle.jl:59,236-240).  devices: list of device
+    indices (default: every visible GPU); one device listed n times is the one-GPU rehearsal."""
+
+    def __init__(self, devices=None):
+        self._lib = _lib.load()
+        if devices is None:
+            devices = list(range(device_count()))
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _lib.check(self._lib.ray_group_create(arr, len(devices), C.byref(h)))
+        self.handle, self.devices = h, list(devices)
+        n, r = C.c_int(), C.c_int()
+        _lib.check(self._lib.ray_group_size(h, C.byref(n), C.byref(r)))
+        self.size, self.uses_rccl = n.value, bool(r.value)
+        self._media = []
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ray_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_arith(self, arith):
+        _lib.check(self._lib.ray_group_set_arith(self.handle, int(arith)))
+
+    def grid_medium(self, c, ext):
+        c = np.asfortranarray(c, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.check(self._lib.ray_group_medium_create_grid(self.handle, _ptr(c), c.shape[0], float(ext), C.byref(h)))
+        return _GroupMedium(self, h)
+
+    def sinprod_medium(self, sp):
+        h = C.c_void_p()
+        _lib.check(self._lib.ray_group_medium_create_sinprod(self.handle, *sp.params, C.byref(h)))
+        return _GroupMedium(self, h)
+
+    def ScatterRelation(self, med, ns, nd, dt, dir=(0.0, math.pi), *, ob=None, time_unit=TIME_SECONDS, src_begin=0,
+                        src_end=None, max_steps=0, info=False, keep_on_device=False):
+        """ScatterRelation / ScatterRelationObstacle over the group: member k shoots theta-block k."""
+        src_end = ns if src_end is None else src_end
+        num = (src_end - src_begin) * nd
+        m = None if keep_on_device else np.zeros((num, 9), dtype=np.float64, order="F")
+        st, nst, nrf = (np.zeros(num, dtype=np.int32) for _ in range(3))
+        prm = _lib.ShootParams(ns, nd, src_begin, src_end, float(dir[0]), float(dir[1]), float(dt), time_unit, max_steps)
+        obs = ob._struct() if ob is not None else None
+        _lib.check(self._lib.ray_group_shoot_to_exit(self.handle, med.handle, C.byref(obs) if obs else None, C.byref(prm),
+                                                     _ptr(m), max(num, 1), _ptr(st), _ptr(nst), _ptr(nrf)))
+        if info:
+            return m, {"status": st, "nsteps": nst, "nreflect": nrf}
+        return m
+
+    def set_observation(self, obs):
+        obs = np.asfortranarray(obs, dtype=np.float64)
+        _lib.check(self._lib.ray_group_set_observation(self.handle, _ptr(obs), obs.shape[0], max(obs.shape[0], 1)))
+        self._num = obs.shape[0]
+
+    def misfit(self, perc_thresh=0.2):
+        num = self._num
+        out = np.zeros(2)
+        mask = np.zeros(num, dtype=np.uint8)
+        mism = np.zeros(4 * num)
+        _lib.check(self._lib.ray_group_misfit(self.handle, _ptr(out), _ptr(mask), float(perc_thresh), _ptr(mism)))
+        return {"mismatch": mism, "sum_mismatch2": out[0], "sum_target2": out[1],
+                "objective": math.sqrt(out[0] / out[1]) if out[1] > 0 else float("nan"), "mask": mask}
+
+    def counters(self):
+        c = _lib.Counters()
+        _lib.check(self._lib.ray_group_get_counters(self.handle, C.byref(c)))
+        return {"rays": c.rays, "ray_steps": c.ray_steps, "launches": c.launches, "kernel_ms": c.kernel_ms}
+
+
+class _GroupMedium:
+    def __init__(self, group, handle):
+        self.group, self.handle = group, handle
+
+    def update(self, c):
+        c = np.asfortranarray(c, dtype=np.float64)
+        _lib.check(self.group._lib.ray_group_medium_update_grid(self.handle, _ptr(c)))
+
+    def close(self):
+        if self.handle:
+            self.group._lib.ray_group_medium_destroy(self.handle)
+            self.handle = None
+
+
 def _resolve(c, gradc, ctx):
     if gradc is not None and gradc is not c:
         raise RayError("pass the medium descriptor itself (or None) as its gradient: closures "

@@ -81,6 +81,18 @@ SIGNATURES = {
     "ray_classify_dev": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp],
     "ray_misfit": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_misfit_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
+    "ray_group_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)],
+    "ray_group_destroy": [_vp],
+    "ray_group_size": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "ray_group_set_arith": [_vp, C.c_int],
+    "ray_group_medium_create_grid": [_vp, _vp, C.c_int, _f64, C.POINTER(_vp)],
+    "ray_group_medium_create_sinprod": [_vp, _f64, _f64, _f64, _f64, _f64, C.POINTER(_vp)],
+    "ray_group_medium_update_grid": [_vp, _vp],
+    "ray_group_medium_destroy": [_vp],
+    "ray_group_shoot_to_exit": [_vp, _vp, C.POINTER(Obstacle), C.POINTER(ShootParams), _vp, _i64, _vp, _vp, _vp],
+    "ray_group_set_observation": [_vp, _vp, _i64, _i64],
+    "ray_group_misfit": [_vp, _vp, _vp, _f64, _vp],
+    "ray_group_get_counters": [_vp, C.POINTER(Counters)],
     "ray_misfit_static_dev": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _f64, _vp],
     "ray_ctx_enable_timing": [_vp, C.c_int],
     "ray_get_counters": [_vp, C.POINTER(Counters)],

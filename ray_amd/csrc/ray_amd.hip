@@ -2001,3 +2001,5 @@ int ray_reset_counters(ray_ctx *ctx)
 }
 
 } // extern "C"
+
+#include "ray_group.h"

@@ -1,0 +1,396 @@
+// ray_group.h -- node-wide fan-out behind the C ABI (included at the end of ray_amd.hip).
+//
+// The reference spreads one ScatterRelation / ScatterForwardOperator call over its workers itself:
+// addprocs(3) (NonObstacleDemo.jl:1, ObstacleDemo.jl:1), `@sync @parallel` (NonObstacle.jl:59, Obstacle.jl:16),
+// per-pid remotecall_wait (NonObstacle.jl:236-240), data through SharedArrays, and sums the misfit serially
+// on the master (NonObstacle.jl:336,372).  Here ONE host process drives every GPU of the node: a ray_group
+// holds one ray_ctx per device, a call launches every member's theta-block (contiguous sources, sizes differ
+// by at most one) asynchronously, each member's slab lands in the caller's column-major m, and the only
+// exchange is ONE ncclAllReduce(sum, f64) of {sum mismatch^2, sum target^2} over RCCL (xGMI on the box).
+// A group may name one device several times (rehearsal on a one-GPU box): RCCL refuses two ranks on one
+// device, so such a group folds the members' partial sums with a one-block kernel on that device, in member
+// order -- same device memory, no collective needed.
+#pragma once
+#include <rccl/rccl.h>
+
+struct GroupMember {
+    ray_ctx *ctx = nullptr;
+    int device = 0;
+    // slab of the last ray_group_shoot_to_exit: rows [row0, row0 + rows) of the caller's m, ld = max(rows, 1)
+    int64_t row0 = 0, rows = 0;
+    double *d_m = nullptr;      size_t m_cap = 0;
+    int32_t *d_int = nullptr;   size_t int_cap = 0;     // status | nsteps | nreflect, rows each
+    double *d_obs = nullptr;    size_t obs_cap = 0;
+    int64_t obs_rows = -1;
+    uint8_t *d_mask = nullptr;  size_t mask_cap = 0;
+    double *d_mis = nullptr;    size_t mis_cap = 0;
+    double *d_sums = nullptr;                           // [0..2) own sums, [2..4) reduced
+    hipEvent_t done = nullptr;
+};
+
+struct ray_group {
+    std::vector<GroupMember> mem;
+    bool use_rccl = false;
+    std::vector<ncclComm_t> comms;
+    const double **d_ptrs = nullptr;                    // fold path: the members' d_sums, on device mem[0].device
+    std::vector<ray_group_medium *> media;
+};
+
+struct ray_group_medium {
+    ray_group *g = nullptr;
+    std::vector<ray_medium *> med;                      // one per member, tables replicated
+};
+
+// fold path (all members on one device): out[0..2) = sum over members of their {sum mismatch^2, sum target^2},
+// in member order (fixed -> reproducible)
+__global__ void k_group_fold(const double *const *parts, int n, double *out)
+{
+    if (threadIdx.x < 2) {
+        double s = parts[0][threadIdx.x];
+        for (int k = 1; k < n; ++k) s = s + parts[k][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+static hipError_t grow(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) *cap = bytes;
+    return e;
+}
+
+static void group_sync_all(ray_group *g)
+{
+    for (GroupMember &m : g->mem) {
+        (void)hipSetDevice(m.device);
+        (void)hipStreamSynchronize(m.ctx->stream);
+    }
+}
+
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            return fail(RAY_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
+    } while (0)
+
+// theta-block of member k: contiguous, sizes differ by at most one (ray_amd/dist.py theta_block)
+static void member_block(int n, int k, int G, int *b, int *e)
+{
+    const int base = n / G, rem = n % G;
+    *b = k * base + std::min(k, rem);
+    *e = *b + base + (k < rem ? 1 : 0);
+}
+
+extern "C" {
+
+int ray_group_destroy(ray_group *g)
+{
+    if (!g) return RAY_OK;
+    group_sync_all(g);
+    for (ray_group_medium *gm : g->media) {             // detach: their own destroy frees the struct only
+        for (ray_medium *m : gm->med) ray_medium_destroy(m);
+        gm->med.clear();
+        gm->g = nullptr;
+    }
+    for (ncclComm_t c : g->comms) (void)ncclCommDestroy(c);
+    for (GroupMember &m : g->mem) {
+        (void)hipSetDevice(m.device);
+        if (m.d_m) (void)hipFree(m.d_m);
+        if (m.d_int) (void)hipFree(m.d_int);
+        if (m.d_obs) (void)hipFree(m.d_obs);
+        if (m.d_mask) (void)hipFree(m.d_mask);
+        if (m.d_mis) (void)hipFree(m.d_mis);
+        if (m.d_sums) (void)hipFree(m.d_sums);
+        if (m.done) (void)hipEventDestroy(m.done);
+        if (m.ctx) ray_ctx_destroy(m.ctx);
+    }
+    if (g->d_ptrs) { (void)hipSetDevice(g->mem[0].device); (void)hipFree(g->d_ptrs); }
+    delete g;
+    return RAY_OK;
+}
+
+int ray_group_create(const int *devices, int n, ray_group **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return fail(RAY_ERR_INVALID, "ray_group_create: 1..64 devices");
+    ray_group *g = new ray_group;
+    g->mem.resize((size_t)n);
+    bool distinct = true;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < k; ++j) distinct = distinct && devices[k] != devices[j];
+    for (int k = 0; k < n; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        m.device = devices[k];
+        int rc = ray_ctx_create(devices[k], &m.ctx);
+        if (rc) { const std::string msg = g_err; ray_group_destroy(g); return fail(rc, msg); }
+        hipError_t e = hipMalloc((void **)&m.d_sums, 4 * sizeof(double));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m.done, hipEventDisableTiming);
+        if (e != hipSuccess) { ray_group_destroy(g); return fail(RAY_ERR_HIP, std::string("ray_group_create: ") + hipGetErrorString(e)); }
+    }
+    if (distinct) {
+        // single-process multi-GPU communicator: one rank per device, collectives issued between
+        // ncclGroupStart / ncclGroupEnd from this thread
+        g->comms.resize((size_t)n);
+        ncclResult_t r = ncclCommInitAll(g->comms.data(), n, devices);
+        if (r != ncclSuccess) {
+            g->comms.clear();
+            ray_group_destroy(g);
+            return fail(RAY_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        }
+        g->use_rccl = true;
+    } else {
+        for (int k = 1; k < n; ++k)
+            if (devices[k] != devices[0]) {
+                ray_group_destroy(g);
+                return fail(RAY_ERR_UNSUPPORTED, "ray_group_create: a device may repeat only if ALL members share it (one-GPU rehearsal)");
+            }
+        std::vector<const double *> ptrs((size_t)n);
+        for (int k = 0; k < n; ++k) ptrs[(size_t)k] = g->mem[(size_t)k].d_sums;
+        hipError_t e = hipSetDevice(devices[0]);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->d_ptrs, sizeof(double *) * (size_t)n);
+        if (e == hipSuccess) e = hipMemcpy(g->d_ptrs, ptrs.data(), sizeof(double *) * (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { ray_group_destroy(g); return fail(RAY_ERR_HIP, std::string("ray_group_create: ") + hipGetErrorString(e)); }
+    }
+    *out = g;
+    return RAY_OK;
+}
+
+int ray_group_size(const ray_group *g, int *n, int *uses_rccl)
+{
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    if (n) *n = (int)g->mem.size();
+    if (uses_rccl) *uses_rccl = g->use_rccl ? 1 : 0;
+    return RAY_OK;
+}
+
+int ray_group_set_arith(ray_group *g, int arith)
+{
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    for (GroupMember &m : g->mem) {
+        int rc = ray_ctx_set_arith(m.ctx, arith);
+        if (rc) return rc;
+    }
+    return RAY_OK;
+}
+
+// ---- media: one replica per member ----------------------------------------------------------------------
+static int group_medium_finish(ray_group *g, ray_group_medium *gm, int rc, ray_group_medium **out)
+{
+    if (rc) {
+        const std::string msg = g_err;
+        for (ray_medium *m : gm->med) ray_medium_destroy(m);
+        delete gm;
+        return fail(rc, msg);
+    }
+    g->media.push_back(gm);
+    *out = gm;
+    return RAY_OK;
+}
+
+int ray_group_medium_create_grid(ray_group *g, const double *c_host, int N, double ext, ray_group_medium **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    ray_group_medium *gm = new ray_group_medium;
+    gm->g = g;
+    int rc = RAY_OK;
+    for (GroupMember &m : g->mem) {
+        ray_medium *med = nullptr;
+        if ((rc = ray_medium_create_grid(m.ctx, c_host, N, ext, &med))) break;
+        gm->med.push_back(med);
+    }
+    return group_medium_finish(g, gm, rc, out);
+}
+
+int ray_group_medium_create_sinprod(ray_group *g, double A, double wx, double wy, double gx, double gy, ray_group_medium **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    ray_group_medium *gm = new ray_group_medium;
+    gm->g = g;
+    int rc = RAY_OK;
+    for (GroupMember &m : g->mem) {
+        ray_medium *med = nullptr;
+        if ((rc = ray_medium_create_sinprod(m.ctx, A, wx, wy, gx, gy, &med))) break;
+        gm->med.push_back(med);
+    }
+    return group_medium_finish(g, gm, rc, out);
+}
+
+int ray_group_medium_update_grid(ray_group_medium *gm, const double *c_host)
+{
+    if (!gm || !gm->g) return fail(RAY_ERR_INVALID, "null / detached group medium");
+    for (ray_medium *m : gm->med) {
+        int rc = ray_medium_update_grid(m, c_host);
+        if (rc) return rc;
+    }
+    return RAY_OK;
+}
+
+int ray_group_medium_destroy(ray_group_medium *gm)
+{
+    if (!gm) return RAY_OK;
+    if (gm->g) {
+        forget(gm->g->media, gm);
+        for (ray_medium *m : gm->med) ray_medium_destroy(m);
+    }
+    delete gm;
+    return RAY_OK;
+}
+
+// ---- ScatterRelation / ScatterRelationObstacle over the whole node -----------------------------------------
+int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_obstacle *ob, const ray_shoot_params *prm,
+                            double *m_host, int64_t ld, int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    if (!gm || gm->g != g) return fail(RAY_ERR_INVALID, "group medium belongs to another group");
+    int rc = check_params(prm);
+    if (rc) return rc;
+    const int G = (int)g->mem.size(), nsrc = prm->src_end - prm->src_begin;
+    const int64_t num = (int64_t)nsrc * prm->nd;
+    if (m_host && ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
+    // 1. every member's launch, back to back (asynchronous: the GPUs run concurrently)
+    for (int k = 0; k < G; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        int b, e;
+        member_block(nsrc, k, G, &b, &e);
+        m.row0 = (int64_t)b * prm->nd;
+        m.rows = (int64_t)(e - b) * prm->nd;
+        if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
+        const size_t rows1 = (size_t)std::max<int64_t>(m.rows, 1);
+        hipError_t he = grow((void **)&m.d_m, &m.m_cap, rows1 * 9 * sizeof(double));
+        if (he == hipSuccess) he = grow((void **)&m.d_int, &m.int_cap, rows1 * 3 * sizeof(int32_t));
+        if (he != hipSuccess) { group_sync_all(g); return fail(he == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, std::string("ray_group_shoot_to_exit: ") + hipGetErrorString(he)); }
+        if (m.rows == 0) continue;
+        ray_shoot_params sub = *prm;
+        sub.src_begin = prm->src_begin + b;
+        sub.src_end = prm->src_begin + e;
+        rc = shoot_to_exit_impl(m.ctx, gm->med[(size_t)k], ob, &sub, m.d_m, m.rows, m.d_int, m.d_int + m.rows, m.d_int + 2 * m.rows);
+        if (rc) { group_sync_all(g); return rc; }
+    }
+    // 2. every member's slab into the caller's column-major arrays (rows [row0, row0 + rows) of each column)
+    for (int k = 0; k < G && m_host; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        if (m.rows == 0) continue;
+        if ((rc = use(m.ctx)) || (rc = copy_cols_d2h(m.ctx, m_host + m.row0, ld, m.d_m, m.rows, m.rows, 0, 9))) { group_sync_all(g); return rc; }
+    }
+    for (int k = 0; k < G; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        if (m.rows == 0 || (!status && !nsteps && !nreflect)) continue;
+        hipError_t he = hipSetDevice(m.device);
+        const size_t nb = sizeof(int32_t) * (size_t)m.rows;
+        if (he == hipSuccess && status) he = hipMemcpyAsync(status + m.row0, m.d_int, nb, hipMemcpyDeviceToHost, m.ctx->stream);
+        if (he == hipSuccess && nsteps) he = hipMemcpyAsync(nsteps + m.row0, m.d_int + m.rows, nb, hipMemcpyDeviceToHost, m.ctx->stream);
+        if (he == hipSuccess && nreflect) he = hipMemcpyAsync(nreflect + m.row0, m.d_int + 2 * m.rows, nb, hipMemcpyDeviceToHost, m.ctx->stream);
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_shoot_to_exit: ") + hipGetErrorString(he)); }
+    }
+    // 3. results valid on return
+    for (GroupMember &m : g->mem) {
+        HIPCHK(hipSetDevice(m.device));
+        HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
+// the observation the misfit is taken against (NonObstacle.jl:336 `observation`), sharded like the last shoot
+// and kept resident: rows [row0, row0 + rows) of every column go to the member that owns them
+int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld)
+{
+    if (!g || !obs_host) return fail(RAY_ERR_INVALID, "null group / observation");
+    int64_t total = 0;
+    for (GroupMember &m : g->mem) total += m.rows;
+    if (num != total || ld < num) return fail(RAY_ERR_INVALID, "ray_group_set_observation: num must equal the rows of the last ray_group_shoot_to_exit");
+    for (GroupMember &m : g->mem) {
+        int rc = use(m.ctx);
+        if (rc) { group_sync_all(g); return rc; }
+        const size_t rows1 = (size_t)std::max<int64_t>(m.rows, 1);
+        hipError_t he = grow((void **)&m.d_obs, &m.obs_cap, rows1 * 9 * sizeof(double));
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_set_observation: ") + hipGetErrorString(he)); }
+        m.obs_rows = m.rows;
+        if (m.rows && (rc = copy_cols_h2d(m.ctx, m.d_obs, m.rows, obs_host + m.row0, ld, m.rows, 4, 4))) { group_sync_all(g); return rc; }
+    }
+    for (GroupMember &m : g->mem) {
+        HIPCHK(hipSetDevice(m.device));
+        HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
+// misfit of the resident slabs against the resident observation: per-member reduction kernels, then ONE
+// all-reduce of the two sums (NonObstacle.jl:336,372; ObstacleDemo.jl:219-226 for the mask)
+int ray_group_misfit(ray_group *g, double out[2], uint8_t *mask, double perc_thresh, double *mismatch)
+{
+    if (!g || !out) return fail(RAY_ERR_INVALID, "null group / out");
+    const int G = (int)g->mem.size();
+    int rc;
+    for (GroupMember &m : g->mem) {
+        if (m.obs_rows != m.rows) return fail(RAY_ERR_INVALID, "ray_group_misfit: call ray_group_set_observation after the shoot it belongs to");
+        if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
+        const size_t rows1 = (size_t)std::max<int64_t>(m.rows, 1);
+        hipError_t he = hipSuccess;
+        if (mask) he = grow((void **)&m.d_mask, &m.mask_cap, rows1);
+        if (he == hipSuccess && mismatch) he = grow((void **)&m.d_mis, &m.mis_cap, rows1 * 4 * sizeof(double));
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_misfit: ") + hipGetErrorString(he)); }
+        rc = ray_misfit_dev(m.ctx, m.d_m, m.d_obs, m.rows, std::max<int64_t>(m.rows, 1), m.d_sums, mask ? m.d_mask : nullptr,
+                            perc_thresh, mismatch ? m.d_mis : nullptr);
+        if (rc) { group_sync_all(g); return rc; }
+    }
+    if (g->use_rccl) {
+        NCCLCHK(ncclGroupStart());
+        for (int k = 0; k < G; ++k) {
+            GroupMember &m = g->mem[(size_t)k];
+            ncclResult_t r = ncclAllReduce(m.d_sums, m.d_sums + 2, 2, ncclDouble, ncclSum, g->comms[(size_t)k], m.ctx->stream);
+            if (r != ncclSuccess) { (void)ncclGroupEnd(); group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+        }
+        NCCLCHK(ncclGroupEnd());
+    } else {
+        GroupMember &m0 = g->mem[0];
+        HIPCHK(hipSetDevice(m0.device));
+        for (int k = 1; k < G; ++k) {
+            HIPCHK(hipEventRecord(g->mem[(size_t)k].done, g->mem[(size_t)k].ctx->stream));
+            HIPCHK(hipStreamWaitEvent(m0.ctx->stream, g->mem[(size_t)k].done, 0));
+        }
+        hipLaunchKernelGGL(k_group_fold, dim3(1), dim3(64), 0, m0.ctx->stream, g->d_ptrs, G, m0.d_sums + 2);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        GroupMember &m0 = g->mem[0];
+        HIPCHK(hipSetDevice(m0.device));
+        HIPCHK(hipMemcpyAsync(out, m0.d_sums + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, m0.ctx->stream));
+    }
+    for (GroupMember &m : g->mem) {
+        if (m.rows == 0) continue;
+        HIPCHK(hipSetDevice(m.device));
+        if (mask) HIPCHK(hipMemcpyAsync(mask + m.row0, m.d_mask, (size_t)m.rows, hipMemcpyDeviceToHost, m.ctx->stream));
+        if (mismatch) HIPCHK(hipMemcpyAsync(mismatch + 4 * m.row0, m.d_mis, sizeof(double) * 4 * (size_t)m.rows, hipMemcpyDeviceToHost, m.ctx->stream));
+    }
+    for (GroupMember &m : g->mem) {
+        HIPCHK(hipSetDevice(m.device));
+        HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
+int ray_group_get_counters(ray_group *g, ray_counters *out)
+{
+    if (!g || !out) return fail(RAY_ERR_INVALID, "null group / out");
+    ray_counters acc{};
+    for (GroupMember &m : g->mem) {
+        ray_counters c{};
+        int rc = ray_get_counters(m.ctx, &c);
+        if (rc) return rc;
+        acc.rays += c.rays; acc.ray_steps += c.ray_steps; acc.launches += c.launches;
+        acc.kernel_ms = std::max(acc.kernel_ms, c.kernel_ms);     // the members run concurrently
+    }
+    *out = acc;
+    return RAY_OK;
+}
+
+} // extern "C"

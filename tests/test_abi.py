@@ -31,6 +31,14 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(syms), exported ^ set(syms)
 
 
+def test_library_links_rccl():
+    """the node-wide group entry points issue their one collective through RCCL: libray_amd.so must carry it
+    as a load-time dependency (no dlopen fallbacks)."""
+    from ray_amd import _lib
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl.so" in out and "libamdhip64.so" in out, out
+
+
 def test_product_never_touches_the_oracle():
     """ray_amd/ and include/ must not import, link or mention the oracle."""
     for base in ("ray_amd", "include"):

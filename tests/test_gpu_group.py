@@ -1,0 +1,73 @@
+"""ray_group: the node-wide fan-out behind the C ABI (include/ray_amd.h) -- what the reference's callers get from
+addprocs / @parallel / remotecall_wait (NonObstacle.jl:59,236-240).  On the one-GPU box: a group of n contexts on
+device 0 (members' sums folded on the device) and a one-member group (the RCCL all-reduce path, one rank) must
+both reproduce the single-context results: m / status / step counts / mask / mismatch bit for bit, the two sums
+to 1e-12.  Distinct-device groups run the same code with n ranks; that is unmeasured until an 8-GPU node exists."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]], ids=["rccl-1rank", "fold-2", "fold-5"])
+def test_group_reproduces_single_context(ctx, orc, devices):
+    import ray_amd
+    ns, nd, dt, N = 7, 100, 1e-2, 75
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5)
+    med1 = ray_amd.GridMedium(c, 1.5, ctx)
+    want, winfo = ray_amd.ScatterRelation(med1, None, ns, nd, dt, ctx=ctx, info=True)
+    g = ray_amd.Group(devices)
+    assert g.size == len(devices) and g.uses_rccl == (len(set(devices)) == len(devices))
+    try:
+        med = g.grid_medium(c, 1.5)
+        m, info = g.ScatterRelation(med, ns, nd, dt, info=True)
+        assert np.array_equal(m, want)
+        for k in ("status", "nsteps", "nreflect"):
+            assert np.array_equal(info[k], winfo[k])
+        cnt = g.counters()
+        assert cnt["rays"] == ns * nd and cnt["ray_steps"] == int(winfo["nsteps"].sum())
+        # the observation: a perturbed copy; misfit of the RESIDENT slabs against it
+        rng = np.random.default_rng(5)
+        obs = np.asfortranarray(want * (1 + 0.3 * rng.standard_normal(want.shape) * (rng.random((want.shape[0], 1)) < 0.5)))
+        ref = ray_amd.misfit(want, obs, 0.2, ctx=ctx)
+        g.set_observation(obs)
+        got = g.misfit(0.2)
+        assert np.array_equal(got["mismatch"], ref["mismatch"]) and np.array_equal(got["mask"], ref["mask"])
+        assert got["sum_mismatch2"] == pytest.approx(ref["sum_mismatch2"], rel=1e-12)
+        assert got["sum_target2"] == pytest.approx(ref["sum_target2"], rel=1e-12)
+        # a sub-range of sources, device-resident only, then the misfit again (theta-blocks of [2, 6))
+        assert g.ScatterRelation(med, ns, nd, dt, src_begin=2, src_end=6, keep_on_device=True) is None
+        g.set_observation(obs[2 * nd:6 * nd])
+        got = g.misfit(0.2)
+        ref = ray_amd.misfit(want[2 * nd:6 * nd], obs[2 * nd:6 * nd], 0.2, ctx=ctx)
+        assert np.array_equal(got["mask"], ref["mask"]) and got["sum_mismatch2"] == pytest.approx(ref["sum_mismatch2"], rel=1e-12)
+        # new nodal values on every replica
+        c2 = np.asfortranarray(0.9 * c + 0.1)
+        med.update(c2)
+        med1.update(c2)
+        assert np.array_equal(g.ScatterRelation(med, ns, nd, dt), ray_amd.ScatterRelation(med1, None, ns, nd, dt, ctx=ctx))
+    finally:
+        g.close()
+
+
+def test_group_more_members_than_sources_and_obstacle(ctx, orc):
+    """ns = 2 over three members (one shoots nothing); analytic medium + circle, t in steps (ObstacleDemo.jl:43)."""
+    import ray_amd
+    sp = ray_amd.SinProd.obstacle_demo()
+    want, winfo = ray_amd.ScatterRelationObstacle(sp, None, ray_amd.Circle(0.3), None, 2, 150, 1e-2, ctx=ctx, info=True)
+    g = ray_amd.Group([0, 0, 0])
+    try:
+        med = g.sinprod_medium(sp)
+        m, info = g.ScatterRelation(med, 2, 150, 1e-2, ob=ray_amd.Circle(0.3), time_unit=ray_amd.TIME_STEPS, info=True)
+        assert np.array_equal(m, want) and np.array_equal(info["nreflect"], winfo["nreflect"])
+        g.set_observation(want)
+        r = g.misfit()
+        assert r["sum_mismatch2"] == 0.0 and r["sum_target2"] > 0 and r["mask"].all()
+        with pytest.raises(ray_amd.RayError):
+            ray_amd.Group([0, 0]).set_observation(want)          # no shoot yet: row count does not match
+        with pytest.raises(ray_amd.RayError):
+            g.ScatterRelation(ray_amd.Group([0]).sinprod_medium(sp), 2, 8, 1e-2)   # medium of another group
+    finally:
+        g.close()
