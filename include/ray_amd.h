@@ -218,6 +218,10 @@ int ray_frechet_destroy(ray_frechet *f);
  *   fidelity_update: residual = |M[k,:] x - mismatch[k]| on the selected rows (0 elsewhere; x must be
  *               zero outside Idx to reproduce :359), and where residual < rejection
  *               fidelity[find(M[k,:])] = max(fidelity, 1 - decay*residual)           (:362-367)
+ *   normal_matvec: w = M[order,:]' * (M[order,:] * x) -- the action of the reference's MtM (:353: it forms
+ *               M[order,Idx]' * M[order,Idx] and factorises it, which a 1024^2 grid does not allow; a Krylov
+ *               solve of (MtM + penalty R) x = b needs only this action and normal_diag)       (fp64 atomics)
+ *   normal_diag:   d[j] = sum over the selected rows of M[k,j]^2 = diag(MtM)
  * `_dev` forms take device pointers and are asynchronous on the context's stream.              */
 int ray_frechet_dofs(ray_frechet *f, const double *fidelity, double *dofs);
 int ray_frechet_dofs_dev(ray_frechet *f, const double *fidelity_dev, double *dofs_dev);
@@ -225,6 +229,10 @@ int ray_frechet_matvec(ray_frechet *f, const double *x, double *y);
 int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev);
 int ray_frechet_matvec_t(ray_frechet *f, const double *v, const uint8_t *ray_mask, double *b);
 int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t *ray_mask_dev, double *b_dev);
+int ray_frechet_normal_matvec(ray_frechet *f, const double *x, const uint8_t *ray_mask, double *w);
+int ray_frechet_normal_matvec_dev(ray_frechet *f, const double *x_dev, const uint8_t *ray_mask_dev, double *w_dev);
+int ray_frechet_normal_diag(ray_frechet *f, const uint8_t *ray_mask, double *d);
+int ray_frechet_normal_diag_dev(ray_frechet *f, const uint8_t *ray_mask_dev, double *d_dev);
 int ray_frechet_fidelity_update(ray_frechet *f, const double *x, const double *mismatch,
                                 const uint8_t *ray_mask, double rejection, double decay,
                                 double *fidelity, double *residual);

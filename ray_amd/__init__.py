@@ -542,6 +542,21 @@ class FrechetMatrix:
         _lib.check(self.ctx._lib.ray_frechet_matvec_t(self.handle, _ptr(v), _ptr(mk) if mk is not None else None, _ptr(b)))
         return b
 
+    def normal_matvec(self, x, ray_mask=None):
+        """w = M[order,:]' (M[order,:] x): the action of the reference's MtM (NonObstacle.jl:353) without forming it."""
+        x = self._vec(x, self.shape[1])
+        mk = None if ray_mask is None else self._vec(ray_mask, self.shape[0] // 4, np.uint8)
+        w = np.zeros(self.shape[1])
+        _lib.check(self.ctx._lib.ray_frechet_normal_matvec(self.handle, _ptr(x), _ptr(mk) if mk is not None else None, _ptr(w)))
+        return w
+
+    def normal_diag(self, ray_mask=None):
+        """diag(MtM) over the selected rays."""
+        mk = None if ray_mask is None else self._vec(ray_mask, self.shape[0] // 4, np.uint8)
+        d = np.zeros(self.shape[1])
+        _lib.check(self.ctx._lib.ray_frechet_normal_diag(self.handle, _ptr(mk) if mk is not None else None, _ptr(d)))
+        return d
+
     def fidelity_update(self, correction, mismatch, fidelity, rejection, decay, ray_mask=None):
         """NonObstacle.jl:359-367: returns (fidelity_new, residual); residual is 0 on unselected rows."""
         x = self._vec(correction, self.shape[1])

@@ -73,6 +73,10 @@ SIGNATURES = {
     "ray_frechet_matvec_dev": [_vp, _vp, _vp],
     "ray_frechet_matvec_t": [_vp, _vp, _vp, _vp],
     "ray_frechet_matvec_t_dev": [_vp, _vp, _vp, _vp],
+    "ray_frechet_normal_matvec": [_vp, _vp, _vp, _vp],
+    "ray_frechet_normal_matvec_dev": [_vp, _vp, _vp, _vp],
+    "ray_frechet_normal_diag": [_vp, _vp, _vp],
+    "ray_frechet_normal_diag_dev": [_vp, _vp, _vp],
     "ray_frechet_fidelity_update": [_vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
     "ray_frechet_fidelity_update_dev": [_vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
     "ray_trace_paths": [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp],

@@ -1747,6 +1747,32 @@ int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t 
     return RAY_OK;
 }
 
+int ray_frechet_normal_matvec_dev(ray_frechet *f, const double *x_dev, const uint8_t *ray_mask_dev, double *w_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x_dev || !w_dev || x_dev == w_dev) return fail(RAY_ERR_INVALID, "null argument / x and w must differ");
+    HIPCHK(hipMemsetAsync(w_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_normal_matvec, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
+                       f->d_indices, f->d_data, x_dev, ray_mask_dev, 4 * f->num, w_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
+int ray_frechet_normal_diag_dev(ray_frechet *f, const uint8_t *ray_mask_dev, double *d_dev)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!d_dev) return fail(RAY_ERR_INVALID, "null argument");
+    HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
+    if (f->num == 0) return RAY_OK;
+    hipLaunchKernelGGL(k_csr_normal_diag, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
+                       f->d_indices, f->d_data, ray_mask_dev, 4 * f->num, d_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
 int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const double *mismatch_dev,
                                     const uint8_t *ray_mask_dev, double rejection, double decay,
                                     double *fidelity_dev, double *residual_dev)
@@ -1815,6 +1841,36 @@ int ray_frechet_matvec_t(ray_frechet *f, const double *v, const uint8_t *ray_mas
     if (ray_mask && (rc = mi.up(f->ctx, ray_mask, (size_t)f->num))) return rc;
     if ((rc = ray_frechet_matvec_t_dev(f, vi.d.as<double>(), ray_mask ? mi.d.as<uint8_t>() : nullptr, out.d.as<double>()))) return rc;
     if ((rc = out.down(f->ctx, b, (size_t)f->N * f->N * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+int ray_frechet_normal_matvec(ray_frechet *f, const double *x, const uint8_t *ray_mask, double *w)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!x || !w) return fail(RAY_ERR_INVALID, "null argument");
+    const size_t n2 = (size_t)f->N * f->N;
+    Staged xi, mi, out;
+    if ((rc = xi.up(f->ctx, x, n2 * 8)) || (rc = out.up(f->ctx, nullptr, n2 * 8))) return rc;
+    if (ray_mask && (rc = mi.up(f->ctx, ray_mask, (size_t)f->num))) return rc;
+    if ((rc = ray_frechet_normal_matvec_dev(f, xi.d.as<double>(), ray_mask ? mi.d.as<uint8_t>() : nullptr, out.d.as<double>()))) return rc;
+    if ((rc = out.down(f->ctx, w, n2 * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
+    return RAY_OK;
+}
+
+int ray_frechet_normal_diag(ray_frechet *f, const uint8_t *ray_mask, double *d)
+{
+    int rc = check_frechet(f);
+    if (rc) return rc;
+    if (!d) return fail(RAY_ERR_INVALID, "null argument");
+    const size_t n2 = (size_t)f->N * f->N;
+    Staged mi, out;
+    if ((rc = out.up(f->ctx, nullptr, n2 * 8))) return rc;
+    if (ray_mask && (rc = mi.up(f->ctx, ray_mask, (size_t)f->num))) return rc;
+    if ((rc = ray_frechet_normal_diag_dev(f, ray_mask ? mi.d.as<uint8_t>() : nullptr, out.d.as<double>()))) return rc;
+    if ((rc = out.down(f->ctx, d, n2 * 8))) return rc;
     HIPCHK(hipStreamSynchronize(f->ctx->stream));
     return RAY_OK;
 }

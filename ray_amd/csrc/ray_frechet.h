@@ -742,6 +742,36 @@ __global__ __launch_bounds__(256) void k_csr_matvec_t(const int64_t *__restrict_
     for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) unsafeAtomicAdd(&b[indices[k]], data[k] * vr);
 }
 
+// The normal operator of the selected rays without forming it (the reference forms MtM = M[order,Idx]' * M[order,Idx],
+// NonObstacle.jl:353; at N = 1024 that product is out of reach, a Krylov solve needs only its action):
+//   w += M[order,:]' (M[order,:] x), one wave per row: dot with x, then scatter row * dot (the row comes back from L2)
+__global__ __launch_bounds__(256) void k_csr_normal_matvec(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                           const double *__restrict__ data, const double *__restrict__ x,
+                                                           const uint8_t *__restrict__ ray_mask, int64_t nrows, double *__restrict__ w)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    if (ray_mask && !ray_mask[row >> 2]) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    double s = 0;
+    for (int64_t k = b + lane; k < e; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
+    s = wave_sum_f64(s);
+    for (int64_t k = b + lane; k < e; k += 64) unsafeAtomicAdd(&w[indices[k]], data[k] * s);
+}
+
+//   d[j] += sum over the selected rows of M[k,j]^2 = diag(MtM): the Jacobi preconditioner of that solve
+__global__ __launch_bounds__(256) void k_csr_normal_diag(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                         const double *__restrict__ data, const uint8_t *__restrict__ ray_mask,
+                                                         int64_t nrows, double *__restrict__ d)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    if (ray_mask && !ray_mask[row >> 2]) return;
+    const int lane = threadIdx.x & 63;
+    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) unsafeAtomicAdd(&d[indices[k]], data[k] * data[k]);
+}
+
 __device__ __forceinline__ void atomic_max_f64(double *addr, double v)
 {
     unsigned long long *a = reinterpret_cast<unsigned long long *>(addr);

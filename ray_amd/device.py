@@ -45,3 +45,30 @@ def misfit_dev(ctx, m_ptr, obs_ptr, num, ld, out_ptr, *, mask_ptr=0, perc_thresh
     """out_ptr -> 2 doubles in HBM: {sum mismatch^2, sum target^2} (what the all-reduce carries)."""
     _lib.check(ctx._lib.ray_misfit_dev(ctx.handle, _vp(m_ptr), _vp(obs_ptr), num, ld, _vp(out_ptr),
                                        _vp(mask_ptr), float(perc_thresh), _vp(mismatch_ptr)))
+
+
+# ---- the loop passes over a device-resident Frechet matrix, device vectors (NonObstacle.jl:340-367) ----------
+def frechet_dofs_dev(F, fidelity_ptr, dofs_ptr):
+    _lib.check(F.ctx._lib.ray_frechet_dofs_dev(F.handle, _vp(fidelity_ptr), _vp(dofs_ptr)))
+
+
+def frechet_matvec_dev(F, x_ptr, y_ptr):
+    _lib.check(F.ctx._lib.ray_frechet_matvec_dev(F.handle, _vp(x_ptr), _vp(y_ptr)))
+
+
+def frechet_matvec_t_dev(F, v_ptr, mask_ptr, b_ptr):
+    _lib.check(F.ctx._lib.ray_frechet_matvec_t_dev(F.handle, _vp(v_ptr), _vp(mask_ptr), _vp(b_ptr)))
+
+
+def frechet_normal_matvec_dev(F, x_ptr, mask_ptr, w_ptr):
+    """w = M[order,:]' (M[order,:] x) -- one launch per Krylov iteration."""
+    _lib.check(F.ctx._lib.ray_frechet_normal_matvec_dev(F.handle, _vp(x_ptr), _vp(mask_ptr), _vp(w_ptr)))
+
+
+def frechet_normal_diag_dev(F, mask_ptr, d_ptr):
+    _lib.check(F.ctx._lib.ray_frechet_normal_diag_dev(F.handle, _vp(mask_ptr), _vp(d_ptr)))
+
+
+def frechet_fidelity_update_dev(F, x_ptr, mismatch_ptr, mask_ptr, rejection, decay, fidelity_ptr, residual_ptr=0):
+    _lib.check(F.ctx._lib.ray_frechet_fidelity_update_dev(F.handle, _vp(x_ptr), _vp(mismatch_ptr), _vp(mask_ptr),
+                                                          float(rejection), float(decay), _vp(fidelity_ptr), _vp(residual_ptr)))
