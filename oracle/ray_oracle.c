@@ -158,30 +158,39 @@ int orc_discrete_hamilton(const double X[4], const double *eval, const double *g
 
 /* ---- "fused" flavour --------------------------------------------------------------------------
  * The reference evaluates these functions under @fastmath (NonObstacle.jl:1,6,30,54), which lets
- * the compiler contract a*b+c into one fused multiply-add.  This flavour spells out one such
- * contraction explicitly (the one the HIP kernels use in RAY_ARITH_FUSED), so that the kernel
- * can be checked bit for bit; against the as-written flavour above it differs by rounding only.
- *   cell index  trunc(fma(x, rh, nb)),  rh = 1/h, nb = -p[1]*rh   (trunc == floor for q >= 0; the
- *               reference's behaviour is undefined below the grid anyway: q in (-1,0) -> cell 1)
- *   dot         fma(dx, fma(dy, t3, t1), fma(dy, t2, t0))
+ * the compiler reassociate and contract.  This flavour spells out ONE such evaluation explicitly --
+ * the one the HIP kernels use in RAY_ARITH_FUSED -- so that the kernel can be checked bit for bit;
+ * against the as-written flavour above it differs by rounding only (tests bound it at 1e-10 with
+ * identical events).
+ *   cell coordinate  q = fma(x, rh, nb),  rh = RN(1/h), nb = RN(-p[1]*rh);  cell = trunc(q)  (== floor
+ *               for q >= 0; the reference is undefined below the grid anyway: q in (-1,0) -> cell 1)
+ *   in-cell offset   in CELL units, u = q - floor(q), kept below 1 (what v_fract_f64 returns), in place of
+ *               dx = x - p[I]: algebraically u = dx/h
+ *   dot         with the coefficients in cell units, t' = t .* [1, h, h, h*h] (one rounding each):
+ *               fma(u, fma(v, t3', t1'), fma(v, t2', t0))
  *   tau         fma(py, py, px*px);  H[2:3] = (-g) * (c*tau)
  *   RK4         Y = fma(H, dt/2, X) / fma(H, dt, X);  acc = fma(2, H, acc);
  *               X += fma(acc + H4, dt*RN(1/6), X)                                              */
-static int cell_index_fused(double x, double rh, double nb, int N, int *oob)
+static int cell_index_fused(double x, double rh, double nb, int N, int *oob, double *u)
 {
-    double q = trunc(fma(x, rh, nb));
+    double q = fma(x, rh, nb);
+    double f = q - floor(q);
+    if (f >= 1.0) f = 0x1.fffffffffffffp-1;               /* q = -tiny: the subtraction rounds to 1 */
+    *u = f;
+    q = trunc(q);
     int I;
     if (!(q > -1.0)) { I = 1; *oob = 1; }                 /* q <= -1 or NaN */
     else if (q > (double)(N - 3)) { I = N - 2; *oob = 1; }
     else I = (int)q + 1;
     return I;
 }
-static double zdot_fused(double dx, double dy, double dxdy, const double *tab, int64_t base,
+static double zdot_fused(double u, double v, double h, const double *tab, int64_t base,
                          int64_t plane, int k0)
 {
-    (void)dxdy;
-    return fma(dx, fma(dy, tab[base + (k0 + 3) * plane], tab[base + (k0 + 1) * plane]),
-               fma(dy, tab[base + (k0 + 2) * plane], tab[base + (k0 + 0) * plane]));
+    const double h2 = h * h;
+    const double t1 = tab[base + (k0 + 1) * plane] * h, t2 = tab[base + (k0 + 2) * plane] * h;
+    const double t3 = tab[base + (k0 + 3) * plane] * h2;
+    return fma(u, fma(v, t3, t1), fma(v, t2, tab[base + (k0 + 0) * plane]));
 }
 int orc_discrete_hamilton_fused(const double X[4], const double *eval, const double *grad,
                                 const double *p, int N, double H[4])
@@ -190,14 +199,13 @@ int orc_discrete_hamilton_fused(const double X[4], const double *eval, const dou
     const int64_t n1 = N - 1, n2 = N - 2;
     double h = p[1] - p[0];
     double rh = 1.0 / h, nb = -p[0] * rh;
-    int I = cell_index_fused(X[0], rh, nb, N, &oob);
-    int J = cell_index_fused(X[1], rh, nb, N, &oob);
-    double dx = X[0] - p[I - 1], dy = X[1] - p[J - 1];
-    double dxdy = dx * dy;
+    double u, v;
+    int I = cell_index_fused(X[0], rh, nb, N, &oob, &u);
+    int J = cell_index_fused(X[1], rh, nb, N, &oob, &v);
     double tau = fma(X[3], X[3], X[2] * X[2]);
-    double c = zdot_fused(dx, dy, dxdy, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
-    double gcX = zdot_fused(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 0);
-    double gcY = zdot_fused(dx, dy, dxdy, grad, (I - 1) + (J - 1) * n2, n2 * n2, 4);
+    double c = zdot_fused(u, v, h, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
+    double gcX = zdot_fused(u, v, h, grad, (I - 1) + (J - 1) * n2, n2 * n2, 0);
+    double gcY = zdot_fused(u, v, h, grad, (I - 1) + (J - 1) * n2, n2 * n2, 4);
     double c2 = c * c, w = c * tau;
     H[0] = c2 * X[2];
     H[1] = c2 * X[3];
@@ -585,23 +593,26 @@ static void point_eval(const double X[4], const double *eval, const double *grad
     const int64_t n1 = N - 1, n2 = N - 2;
     double h = p[1] - p[0];
     q->oob = 0;
+    double u = 0, v = 0;
     if (arith) {
         double rh = 1.0 / h, nb = -p[0] * rh;
-        q->I = cell_index_fused(X[0], rh, nb, N, &q->oob);
-        q->J = cell_index_fused(X[1], rh, nb, N, &q->oob);
+        q->I = cell_index_fused(X[0], rh, nb, N, &q->oob, &u);
+        q->J = cell_index_fused(X[1], rh, nb, N, &q->oob, &v);
+        q->dx = u * h;                                   /* physical offsets for the hess look-up and dV */
+        q->dy = v * h;
     } else {
         q->I = cell_index(X[0], p[0], h, N, &q->oob);
         q->J = cell_index(X[1], p[0], h, N, &q->oob);
+        q->dx = X[0] - p[q->I - 1];
+        q->dy = X[1] - p[q->J - 1];
     }
-    q->dx = X[0] - p[q->I - 1];
-    q->dy = X[1] - p[q->J - 1];
     double dxdy = q->dx * q->dy;
     int64_t be = (q->I - 1) + (q->J - 1) * n1, bg = (q->I - 1) + (q->J - 1) * n2;
     if (arith) {
         q->tau = fma(X[3], X[3], X[2] * X[2]);
-        q->c = zdot_fused(q->dx, q->dy, dxdy, eval, be, n1 * n1, 0);
-        q->gcX = zdot_fused(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 0);
-        q->gcY = zdot_fused(q->dx, q->dy, dxdy, grad, bg, n2 * n2, 4);
+        q->c = zdot_fused(u, v, h, eval, be, n1 * n1, 0);
+        q->gcX = zdot_fused(u, v, h, grad, bg, n2 * n2, 0);
+        q->gcY = zdot_fused(u, v, h, grad, bg, n2 * n2, 4);
     } else {
         q->tau = X[2] * X[2] + X[3] * X[3];
         q->c = zdot(q->dx, q->dy, dxdy, eval, be, n1 * n1, 0);

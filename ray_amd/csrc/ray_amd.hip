@@ -32,8 +32,10 @@ __device__ __forceinline__ void q4(const double *c, int N, int i, int j, double 
     q[3] = (((c11 + c00) - c10) - c01) / (dx * dx);
 }
 
-__global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__ c, int N, double dx,
-                                                       double *__restrict__ rec)
+// recf: the same record with coefficient k of every quadruple scaled by [1, h, h, h*h] (h = p[2] - p[1], the
+// cell size the kFused flavour's cell coordinate is built on; one rounding per coefficient).
+__global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__ c, int N, double dx, double h,
+                                                       double *__restrict__ rec, double *__restrict__ recf)
 {
     const int n1 = N - 1;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,6 +60,13 @@ __global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__
     double2 *r = reinterpret_cast<double2 *>(rec) + (size_t)id * 6;
 #pragma unroll
     for (int k = 0; k < 6; ++k) r[k] = make_double2(out[2 * k], out[2 * k + 1]);
+    const double h2 = h * h;
+    double2 *rf = reinterpret_cast<double2 *>(recf) + (size_t)id * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rf[2 * k] = make_double2(out[4 * k], out[4 * k + 1] * h);
+        rf[2 * k + 1] = make_double2(out[4 * k + 2] * h, out[4 * k + 3] * h2);
+    }
 }
 
 struct ShootArgs {
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         valid = r < a.num;
     }
     GridAcc acc{};
-    if (MED == kGrid) acc = grid_acc_setup(a.med.g);
+    if (MED == kGrid) acc = grid_acc_setup<AR == kExact>(a.med.g);
     double X[4] = {0, 0, 1, 0};                             // harmless state for padding lanes
     int st = 0, oob = 0;
     if (valid) {
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
             const double theta = a.src[il] + a.half_pi + a.direct[j];
             double sn, cs;
             sincos(theta, &sn, &cs);
-            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, lds_nodes(), sx, sy, oob)
+            const double c0 = (MED == kGrid) ? speed_grid(a.med.g, AR == kExact ? lds_nodes() : a.med.g.p, sx, sy, oob)
                             : (MED == kRadial) ? speed_radial(a.med.rd, sx, sy)
                                              : speed_sinprod(a.med.sp, sx, sy);
             X[0] = sx; X[1] = sy; X[2] = cs / c0; X[3] = sn / c0;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < a.num;
-    const GridAcc acc = grid_acc_setup(a.med.g);
+    const GridAcc acc = grid_acc_setup<AR == kExact>(a.med.g);
     double X[4] = {0, 0, 1, 0};
     double T = 0;
     int steps = 0, st = 0, oob = 0, it = 0;
@@ -617,7 +626,7 @@ struct ray_medium {
     RadialDev rd{};
     int N = 0;
     double ext = 0;
-    double *d_c = nullptr, *d_rec = nullptr, *d_p = nullptr;
+    double *d_c = nullptr, *d_rec = nullptr, *d_recf = nullptr, *d_p = nullptr;
     double *d_hrec = nullptr;                  // hess records, built on first use by the Frechet path
     bool hess_valid = false;
     std::vector<double> p;                     // host copy of the nodes
@@ -857,7 +866,7 @@ static int build_tables(ray_medium *med)
     const int64_t cells = (int64_t)n1 * n1;
     const double dx = 2 * med->ext / (med->N - 1);                      // NonObstacle.jl:191
     hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                       med->d_c, med->N, dx, med->d_rec);
+                       med->d_c, med->N, dx, med->p[1] - med->p[0], med->d_rec, med->d_recf);
     HIPCHK(hipGetLastError());
     med->hess_valid = false;
     return RAY_OK;
@@ -892,6 +901,7 @@ int ray_medium_create_grid(ray_ctx *ctx, const double *c_host, int N, double ext
     const size_t nc = (size_t)N * N, nr = (size_t)(N - 1) * (N - 1) * 12;
     hipError_t e = hipMalloc((void **)&m->d_c, nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_rec, nr * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_recf, nr * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_p, (size_t)N * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(m->d_p, m->p.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
@@ -984,9 +994,10 @@ static void detach_medium(ray_medium *med)
 {
     if (med->d_c) (void)hipFree(med->d_c);
     if (med->d_rec) (void)hipFree(med->d_rec);
+    if (med->d_recf) (void)hipFree(med->d_recf);
     if (med->d_p) (void)hipFree(med->d_p);
     if (med->d_hrec) (void)hipFree(med->d_hrec);
-    med->d_c = med->d_rec = med->d_p = med->d_hrec = nullptr;
+    med->d_c = med->d_rec = med->d_recf = med->d_p = med->d_hrec = nullptr;
     med->ctx = nullptr;
 }
 
@@ -1009,7 +1020,7 @@ static MediumDev medium_dev(const ray_medium *m)
     d.sp = m->sp;
     d.rd = m->rd;
     if (m->kind == kGrid) {
-        d.g.rec = m->d_rec; d.g.hrec = m->d_hrec; d.g.p = m->d_p; d.g.N = m->N;
+        d.g.rec = m->d_rec; d.g.recf = m->d_recf; d.g.hrec = m->d_hrec; d.g.p = m->d_p; d.g.N = m->N;
         d.g.p1 = m->p[0];
         d.g.h = m->p[1] - m->p[0];                                      // NonObstacle.jl:32
         d.g.rh = 1.0 / d.g.h;
@@ -1028,9 +1039,9 @@ static int block_threads()
     }();
     return b;
 }
-static size_t nodes_lds_bytes(const ray_medium *med)
+static size_t nodes_lds_bytes(const ray_medium *med, bool fused)
 {
-    return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads()) : 0;
+    return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads(), !fused) : 0;   // no node table in kFused
 }
 
 // ---- shooting -----------------------------------------------------------------------------------
@@ -1072,11 +1083,11 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
         nblk = (unsigned)(((a.nd + dpw - 1) / dpw) * a.ngroup);
     } else nblk = (unsigned)((a.num + bt - 1) / bt);
     const dim3 grid(nblk), block(bt);
-    const size_t lds = nodes_lds_bytes(med);
+    const bool fused = ctx->arith == RAY_ARITH_FUSED;
+    const size_t lds = nodes_lds_bytes(med, fused);
     if (lds > 160 * 1024) return fail(RAY_ERR_UNSUPPORTED, "grid too large for the LDS node table");
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    const bool fused = ctx->arith == RAY_ARITH_FUSED;
 #define RAY_LAUNCH_SHOOT(MED, OB, AR, PATH, LDS) hipLaunchKernelGGL((k_shoot<MED, OB, AR, PATH>), grid, block, LDS, ctx->stream, a)
 #define RAY_LAUNCH_BY_OB(MED, AR, PATH, LDS)                                  \
     do {                                                                      \
@@ -1307,10 +1318,10 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     const dim3 tgrid((unsigned)((num + block_threads() - 1) / block_threads())), tblock(block_threads());
     if (path_dev) {
         a.path = path_dev; a.npts = npts_dev; a.max_pts = max_pts;
-        if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 1>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace<kExact, 1>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
-    } else if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 0>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
-    else hipLaunchKernelGGL((k_trace<kExact, 0>), tgrid, tblock, nodes_lds_bytes(med), ctx->stream, a);
+        if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 1>), tgrid, tblock, nodes_lds_bytes(med, true), ctx->stream, a);
+        else hipLaunchKernelGGL((k_trace<kExact, 1>), tgrid, tblock, nodes_lds_bytes(med, false), ctx->stream, a);
+    } else if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 0>), tgrid, tblock, nodes_lds_bytes(med, true), ctx->stream, a);
+    else hipLaunchKernelGGL((k_trace<kExact, 0>), tgrid, tblock, nodes_lds_bytes(med, false), ctx->stream, a);
     time_end(ctx, e0, e1);
     HIPCHK(hipGetLastError());
     ctx->rays += (uint64_t)num;

@@ -24,6 +24,9 @@ constexpr int kBisectCap = 200;
 // so one right-hand side touches one or two 128-byte lines instead of 12 planes.
 struct GridDev {
     const double *rec;   // (N-1)*(N-1)*12
+    const double *recf;  // the same records in CELL units for the kFused flavour: coefficient k of each
+                         // bilinear quadruple times [1, h, h, h*h] (one rounding each), so that the in-cell
+                         // offsets enter as u = dx/h, v = dy/h in [0,1) -- see cell_of<kFused>
     const double *hrec;  // (N-1)*(N-1)*12 hess records (Frechet path only; may be null)
     const double *p;     // N nodes, linspace(-ext, ext, N)
     int N;
@@ -85,21 +88,52 @@ struct RecState {
     unsigned addr = 0;
 };
 
-__host__ __device__ inline size_t grid_lds_bytes(int N, int block)
+// kFused keeps no node table (its in-cell offsets come from the fractional part of the cell coordinate)
+__host__ __device__ inline size_t grid_lds_bytes(int N, int block, bool nodes = true)
 {
-    return (((size_t)N * 8 + 511) & ~(size_t)511) + (size_t)(block / 64) * kWaveLdsBytes;
+    return (nodes ? (((size_t)N * 8 + 511) & ~(size_t)511) : 0) + (size_t)(block / 64) * kWaveLdsBytes;
 }
+
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
 
 extern __shared__ __attribute__((aligned(16))) char ray_smem[];   // [ p | record slots | cell ids ]
 
 __device__ __forceinline__ const double *lds_nodes() { return reinterpret_cast<const double *>(ray_smem); }
 
+// LDS accesses by ABSOLUTE byte address (the dynamic segment's own base folded into the wave offsets once,
+// at set-up): `ray_smem + offset` costs a v_add_u32 of the base -- a link-time 0 -- on every access.
+typedef double lds_d2v __attribute__((ext_vector_type(2)));
+typedef unsigned lds_u2v __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RAY_LDS_PTR(T, addr) ((__attribute__((address_space(3))) T *)(unsigned)(addr))      // 32-bit LDS pointers
+#else
+#define RAY_LDS_PTR(T, addr) ((__attribute__((address_space(3))) T *)(uintptr_t)(addr))     // host pass: parsed only
+#endif
+__device__ __forceinline__ double2 lds_ld_d2(unsigned addr)
+{
+    const lds_d2v v = *RAY_LDS_PTR(const lds_d2v, addr);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned lds_ld_u32(unsigned addr) { return *RAY_LDS_PTR(const unsigned, addr); }
+__device__ __forceinline__ void lds_st_u32(unsigned addr, unsigned v) { *RAY_LDS_PTR(unsigned, addr) = v; }
+__device__ __forceinline__ void lds_st_u2(unsigned addr, unsigned x, unsigned y)
+{
+    lds_u2v v;
+    v.x = x; v.y = y;
+    *RAY_LDS_PTR(lds_u2v, addr) = v;
+}
+
+template <bool NODES>
 __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
 {
     GridAcc a;
-    double *p_lds = reinterpret_cast<double *>(ray_smem);
-    for (int k = threadIdx.x; k < g.N; k += blockDim.x) p_lds[k] = g.p[k];
-    const unsigned poff = ((unsigned)g.N * 8u + 511u) & ~511u;
+    if (NODES) {
+        double *p_lds = reinterpret_cast<double *>(ray_smem);
+        for (int k = threadIdx.x; k < g.N; k += blockDim.x) p_lds[k] = g.p[k];
+    }
+    const unsigned base = (unsigned)(uintptr_t)(lptr_t)ray_smem;
+    const unsigned poff = base + (NODES ? (((unsigned)g.N * 8u + 511u) & ~511u) : 0u);
     // wave-uniform by construction; readfirstlane tells the compiler so (LDS bases live in SGPRs)
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     a.wtags = poff + wave * (kTagEntries * 4);
@@ -116,8 +150,8 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
         a.role_poff[sl] = (v - run * 6u) * 16u;
     }
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
-    *reinterpret_cast<int *>(ray_smem + a.wcells + a.lane * 4u) = 0;
-    *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
+    lds_st_u32(a.wcells + a.lane * 4u, 0u);
+    lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
     __syncthreads();
     return a;
 }
@@ -126,9 +160,6 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
 // cells whose grad entry exists (reference: undefined behaviour outside; here flagged): cell_of().
 // v_cvt_i32_f64 saturates and maps NaN to 0; a NaN position is flagged by the callers' own
 // per-step check, so the flag word equals the CPU restatement's in every case.
-typedef const void __attribute__((address_space(1))) *gptr_t;
-typedef void __attribute__((address_space(3))) *lptr_t;
-
 // Wave-cooperative fetch of the 96-byte cell records (ALL 64 lanes must call this together).
 // Lanes are consecutive directions of one source, so along the wavefront the cell index changes
 // only every few lanes: a lane is a "leader" when its cell differs from its left neighbour's.
@@ -150,14 +181,14 @@ __device__ __forceinline__ constexpr unsigned pass_base(int t) { return (64u * t
 template <int T>
 __device__ __forceinline__ unsigned read_cell_of_pass(const GridAcc &a)
 {
-    return *reinterpret_cast<const unsigned *>(ray_smem + a.wcells + a.role_run4[T % 3] + 4u * pass_base(T));
+    return lds_ld_u32(a.wcells + a.role_run4[T % 3] + 4u * pass_base(T));
 }
 template <int T>
 __device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsigned c, unsigned npiece)
 {
     if (a.lane + 64u * T < npiece)
         __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, a.role_poff[T % 3])),
-                                         (lptr_t)(ray_smem + a.wrec + T * 1024u), 16, 0, 0);
+                                         (lptr_t)RAY_LDS_PTR(char, a.wrec + T * 1024u), 16, 0, 0);
 }
 
 #ifdef RAY_STATS
@@ -175,7 +206,7 @@ __device__ __forceinline__ unsigned tag_addr(const GridAcc &a, int i, int j)
     return addr;
 }
 
-__device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
+__device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
 {
 #ifdef RAY_ABLATE_NOFETCH
     asm volatile("" :: "v"(cid));
@@ -196,7 +227,6 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     // (bit 0 is always set)
     const unsigned long long m1 = mask >> 1;
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-    const char *rec = reinterpret_cast<const char *>(g.rec);
 #ifdef RAY_STATS
     if (a.lane == 0) {
         const unsigned nr = npiece / 6u;
@@ -210,10 +240,10 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
     }
 #endif
     // the slots are about to be overwritten: forget what the tags said about them
-    *reinterpret_cast<uint2 *>(ray_smem + a.wtags + a.lane * 8u) = make_uint2(kTagEmpty, kTagEmpty);
+    lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
     if (leader) {
-        *reinterpret_cast<int *>(ray_smem + a.wcells + rank * 4u) = cid;
-        *reinterpret_cast<unsigned *>(ray_smem + tag_addr(a, i, j)) = ((unsigned)cid << 6) | rank;
+        lds_st_u32(a.wcells + rank * 4u, (unsigned)cid);
+        lds_st_u32(tag_addr(a, i, j), ((unsigned)cid << 6) | rank);
     }
     // passes 0 and 1 (<= 21 runs, the common case): both cell-id reads first, then both DMA loads
     unsigned c0 = read_cell_of_pass<0>(a), c1 = read_cell_of_pass<1>(a);
@@ -247,36 +277,35 @@ __device__ __forceinline__ void fetch_records(const GridDev &g, const GridAcc &a
 #endif
     rs.cid = cid;
     rs.addr = mad24(rank, 96u, a.wrec_v);
-    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + rs.addr);
+    asm volatile("" : "+v"(rs.addr));            // computed once: the look-up after this fetch reuses the register
 #pragma unroll
-    for (int k = 0; k < 6; ++k) out[k] = r[k];
+    for (int k = 0; k < 6; ++k) out[k] = lds_ld_d2(rs.addr + 16u * k);
 }
 
 // Look-up through the tags (ALL 64 lanes together): the record of cell `cid` if the last
 // fetch_records() of this wave brought it in -- for this lane or for any other -- else this lane
 // gathers it from memory itself.  Same bytes either way: the path taken never shows in the results.
-__device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
+__device__ __forceinline__ void lookup_records(const char *rec, const GridAcc &a, int i, int j, int cid, double2 out[6], RecState &rs)
 {
 #if defined(RAY_ABLATE_NOFETCH) || defined(RAY_ABLATE_NOCACHE)
-    fetch_records(g, a, i, j, cid, out, rs);
+    fetch_records(rec, a, i, j, cid, out, rs);
     return;
 #endif
     if (__builtin_amdgcn_ballot_w64(cid != rs.cid) == 0) {           // every lane still in the cell it fetched
-        const double2 *r = reinterpret_cast<const double2 *>(ray_smem + rs.addr);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) out[k] = r[k];
+        for (int k = 0; k < 6; ++k) out[k] = lds_ld_d2(rs.addr + 16u * k);
 #ifdef RAY_STATS
         if (a.lane == 0) { atomicAdd(&g_ray_stats[0], 1ull); atomicAdd(&g_ray_stats[11], 1ull); }
 #endif
         return;
     }
-    const unsigned tag = *reinterpret_cast<const unsigned *>(ray_smem + tag_addr(a, i, j));
+    const unsigned tag = lds_ld_u32(tag_addr(a, i, j));
     const unsigned d = tag - ((unsigned)cid << 6);           // = slot on a hit, >= 64 otherwise (kTagEmpty included)
     const bool hit = d < 64u;
     const unsigned slot = d & 63u;                           // a missing lane reads some slot and overwrites it below
-    const double2 *r = reinterpret_cast<const double2 *>(ray_smem + mad24(slot, 96u, a.wrec_v));
+    const unsigned saddr = mad24(slot, 96u, a.wrec_v);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) out[k] = r[k];
+    for (int k = 0; k < 6; ++k) out[k] = lds_ld_d2(saddr + 16u * k);
 #ifdef RAY_STATS
     {
         const unsigned long long mm = __builtin_amdgcn_ballot_w64(!hit);
@@ -288,7 +317,7 @@ __device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &
 #endif
     if (__builtin_amdgcn_ballot_w64(!hit) != 0) {
         if (!hit) {
-            const double2 *src = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(g.rec) + (size_t)cid * 96u);
+            const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)cid * 96u);
 #pragma unroll
             for (int k = 0; k < 6; ++k) out[k] = src[k];
         }
@@ -300,11 +329,16 @@ __device__ __forceinline__ void lookup_records(const GridDev &g, const GridAcc &
 //          order (bit-identical to the un-fused CPU restatement, oracle/ray_oracle.c).  fma is used
 //          only where it provably returns the same bits: x + k*0.5, acc + 2*k (the product is exact)
 //          and the two Markstein quotients (header comment).
-// kFused : the same formulas with multiply-adds contracted, as a compiler is free to do under the
-//          reference's @fastmath (NonObstacle.jl:1,6,30,54): Horner dot products, H*(dt/2) folded
-//          into the stage update, one multiply by RN(1/h) for the cell index.  Differs from kExact
-//          by rounding only (~1e-12 relative on exits, tests/test_gpu_parity.py) and is itself
-//          bit-identical to the oracle's "fused" flavour, which spells out the same contractions.
+// kFused : the same formulas evaluated the way a compiler is free to under the reference's @fastmath
+//          (NonObstacle.jl:1,6,30,54) -- algebraically identical, rounded differently:
+//            cell coordinate  q = fma(x, RN(1/h), RN(-p1/h));  cell = trunc(q);  in-cell offset in CELL units
+//                             u = q - floor(q)  (v_fract_f64) instead of dx = x - p[I]: no node table
+//            records          in cell units (GridDev::recf: coefficients times [1, h, h, h*h]), so that
+//                             t0 + t1 dx + t2 dy + t3 dx dy = fma(u, fma(v, t3', t1'), fma(v, t2', t0))
+//            H*(dt/2) folded into the stage update, tau = fma(py, py, px*px), H[2:3] = (-g) * (c*tau).
+//          Differs from kExact by rounding only (~1e-12 relative on exits, bound 1e-10 with identical
+//          events, tests/test_gpu_parity.py) and is itself bit-identical to the oracle's "fused"
+//          flavour, which spells out the same operations (oracle/ray_oracle.c).
 enum Arith { kExact = 0, kFused = 1 };
 
 // Out-of-grid tracking: a running UNSIGNED maximum of the raw cell indices (a negative index wraps to
@@ -314,24 +348,32 @@ typedef unsigned OobMax;
 __device__ __forceinline__ int oob_hit(const GridDev &g, OobMax m) { return m > (unsigned)(g.N - 3); }
 
 template <int AR>
-__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob, double nb)
+__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob, double nb, double &u)
 {
     // kExact: floor of the correctly rounded quotient.  kFused: one fma, and the conversion's own
     // truncation stands in for floor (equal for q >= 0; q in (-1,0) lands in cell 0 un-flagged,
-    // which the oracle's fused flavour defines the same way).
+    // which the oracle's fused flavour defines the same way); u = fract(q) = q - floor(q), clamped
+    // below 1 by the instruction (v_fract_f64), is the in-cell offset in cell units.
     const double q = (AR == kFused) ? __builtin_fma(x, g.rh, nb)
                                     : __builtin_floor(div_rn(x - g.p1, g.h, g.rh));
     int iraw, i;                                 // v_cvt truncates and saturates; (int)q would be UB out of range
     asm("v_cvt_i32_f64 %0, %1" : "=v"(iraw) : "v"(q));
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(i) : "v"(iraw), "s"(g.N - 3));
+    if (AR == kFused) asm("v_fract_f64 %0, %1" : "=v"(u) : "v"(q));
     oob = (unsigned)iraw > oob ? (unsigned)iraw : oob;
     return i;
 }
 template <int AR>
-__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob) { return cell_of<AR>(x, g, oob, g.nb); }
+__device__ __forceinline__ int cell_of(double x, const GridDev &g, OobMax &oob)
+{
+    double u;
+    return cell_of<AR>(x, g, oob, g.nb, u);
+}
 
 // H = [c^2 p ; -grad c * c * tau] from one cell record and the in-cell offsets (NonObstacle.jl:37-42),
 // in the chosen arithmetic flavour; also returns c, dc/dx, dc/dy, tau for the Jacobian path.
+// kExact: (dx, dy) physical offsets and a record of GridDev::rec; kFused: (dx, dy) = (u, v) in cell units and a
+// record of GridDev::recf.
 template <int AR>
 __device__ __forceinline__ void h_from_record(const double X[4], double dx, double dy, const double2 r[6],
                                               double H[4], double &c, double &gcX, double &gcY, double &tau)
@@ -375,8 +417,9 @@ template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
                                          unsigned long long lm, RecState &rs)
 {
-    int i = cell_of<AR>(X[0], g, oob, a.nb_v);
-    int j = cell_of<AR>(X[1], g, oob, a.nb_v);
+    double dx, dy;                                                   // kFused: set here, in cell units
+    int i = cell_of<AR>(X[0], g, oob, a.nb_v, dx);
+    int j = cell_of<AR>(X[1], g, oob, a.nb_v, dy);
 #ifndef RAY_ABLATE_NOGHOST
     asm("" : "+s"(lm));               // compare afresh (s_cmp_lg_u64): a shared result comes back through a VGPR
     if (lm != ~0ull) {                                                // wave-uniform: bit l = lane l is live
@@ -387,20 +430,20 @@ __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, con
     }
 #endif
     const int cid = (int)mad24((unsigned)j, (unsigned)(g.N - 1), (unsigned)i);
-#ifdef RAY_ABLATE_PCOMP
-    const double pi_ = __builtin_fma((double)i, g.h, g.p1), pj_ = __builtin_fma((double)j, g.h, g.p1);
-#else
-    const double *pt = lds_nodes();
-    const double pi_ = pt[i], pj_ = pt[j];
-#endif
+    double pi_ = 0, pj_ = 0;
+    if (AR == kExact) {
+        const double *pt = lds_nodes();
+        pi_ = pt[i]; pj_ = pt[j];
+    }
+    const char *rec = reinterpret_cast<const char *>(AR == kFused ? g.recf : g.rec);
     double2 r[6];
 #ifdef RAY_ABLATE_HOT
-    fetch_records(g, a, i, j, (cid & 0xff) + 5000, r, rs);     // same run structure, 256-record footprint: always L1-hot
+    fetch_records(rec, a, i, j, (cid & 0xff) + 5000, r, rs);   // same run structure, 256-record footprint: always L1-hot
 #else
-    if (MODE == kLookup) lookup_records(g, a, i, j, cid, r, rs);
-    else fetch_records(g, a, i, j, cid, r, rs);
+    if (MODE == kLookup) lookup_records(rec, a, i, j, cid, r, rs);
+    else fetch_records(rec, a, i, j, cid, r, rs);
 #endif
-    const double dx = X[0] - pi_, dy = X[1] - pj_;
+    if (AR == kExact) { dx = X[0] - pi_; dy = X[1] - pj_; }
     double c, gcX, gcY, tau;
     h_from_record<AR>(X, dx, dy, r, H, c, gcX, gcY, tau);
 }

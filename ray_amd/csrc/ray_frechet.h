@@ -61,18 +61,25 @@ template <int AR>
 __device__ __forceinline__ void point_eval(const GridDev &g, const double X[4], double H[4], PointEval &q, int &oob)
 {
     OobMax om = 0;
-    q.i = cell_of<AR>(X[0], g, om);
-    q.j = cell_of<AR>(X[1], g, om);
+    double u = 0, v = 0;                                    // kFused: in-cell offsets in cell units (ray_device.h)
+    q.i = cell_of<AR>(X[0], g, om, g.nb, u);
+    q.j = cell_of<AR>(X[1], g, om, g.nb, v);
     oob |= oob_hit(g, om);
     const unsigned cid = mad24((unsigned)q.j, (unsigned)(g.N - 1), (unsigned)q.i);
-    const double *pt = lds_nodes();
-    q.dx = X[0] - pt[q.i];
-    q.dy = X[1] - pt[q.j];
-    const double2 *src = reinterpret_cast<const double2 *>(g.rec) + (size_t)cid * 6;
+    const double2 *src = reinterpret_cast<const double2 *>(AR == kFused ? g.recf : g.rec) + (size_t)cid * 6;
     double2 r[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) r[k] = src[k];
-    h_from_record<AR>(X, q.dx, q.dy, r, H, q.c, q.gcX, q.gcY, q.tau);
+    if (AR == kFused) {
+        h_from_record<AR>(X, u, v, r, H, q.c, q.gcX, q.gcY, q.tau);
+        q.dx = u * g.h;                                     // physical offsets for the hess look-up and dV
+        q.dy = v * g.h;
+    } else {
+        const double *pt = lds_nodes();
+        q.dx = X[0] - pt[q.i];
+        q.dy = X[1] - pt[q.j];
+        h_from_record<AR>(X, q.dx, q.dy, r, H, q.c, q.gcX, q.gcY, q.tau);
+    }
 }
 
 __device__ __forceinline__ double bil(double dx, double dy, double dxdy, double2 a, double2 b)
