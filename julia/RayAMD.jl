@@ -8,6 +8,12 @@
 #   ScatterRelationObstacle(c, ∇c, ob, ∇ob, ns, nd, dt)   Obstacle.jl:11
 #   ScatterForwardOperator(c, m, ext, dt)                  NonObstacle.jl:189   (s and sparse M)
 #   NonReflectionTrace(c, m, ext, dt)                      Obstacle.jl:275
+#   NonReflectionPlot(c, m, ext, dt)                       Obstacle.jl:222      (the polylines; plotting stays with the caller)
+#   ScatterRelationObstaclePlot(c, ∇c, ob, ∇ob, ns, nd, dt, rayIndex)   Obstacle.jl:98   (m and the polylines)
+# plus what the loops around them need on the device: the gridded-medium ScatterRelation (BASELINE config 2's
+# composition), classify_rays (Utility.jl:1-39, ObstacleDemo.jl:48-67), the passes over a device-resident Frechet
+# matrix (NonObstacle.jl:340-367) and RayGroup, the node-wide fan-out that replaces addprocs / @parallel
+# (NonObstacle.jl:59,236-240).
 #
 # Only `ccall`; no AMDGPU.jl, no CUDA shims, no CPU fallback (a missing library is an error).
 # Closures cannot cross a C ABI onto a GPU: the medium / obstacle arguments are descriptor values
@@ -24,6 +30,9 @@ using SharedArrays   # NonObstacleReconstruction requires m::SharedArray{Float64
 
 export SinProd, RadialSineSum, smooth_alt, obstacle_alt, Circle, Trefoil, trefoil_demo, smooth_demo, obstacle_demo,
        ScatterRelation, ScatterRelationObstacle, ScatterForwardOperator, NonReflectionTrace,
+       NonReflectionPlot, ScatterRelationObstaclePlot, classify_rays,
+       Frechet, forward_operator_dev, dofs, matvec, rmatvec, normal_matvec, normal_diag, fidelity_update!,
+       RayGroup, set_observation!,
        misfit, set_arith!, ARITH_EXACT, ARITH_FUSED, read_rayfix
 
 const LIB = get(ENV, "RAY_AMD_LIB", joinpath(@__DIR__, "..", "ray_amd", "libray_amd.so"))
@@ -214,6 +223,225 @@ end
 function NonReflectionTrace(c::Matrix{Float64}, m, ext::Float64, dt::Float64)
     m[:, 5:8] = trace(c, m, ext, dt, TRACE_OVERSHOOT)
     m
+end
+
+# ---- the gridded-medium forms of the shooting entry points (BASELINE config 2 = a2's RHS inside a6's loop) ----
+function ScatterRelation(c::Matrix{Float64}, ext::Float64, ns::Int, nd::Int, dt::Float64, dir = (0, pi))
+    m = SharedArray{Float64}((ns * nd, 9))
+    prm = CShootParams(ns, nd, 0, ns, Float64(dir[1]), Float64(dir[2]), dt, TIME_SECONDS, 0)
+    with_medium(c, ext) do med
+        check(ccall((:ray_shoot_to_exit, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CObstacle}, Ref{CShootParams}, Ptr{Cdouble}, Int64,
+                     Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    context(), med, C_NULL, prm, m, ns * nd, C_NULL, C_NULL, C_NULL))
+    end
+    m
+end
+
+function ScatterRelationObstacle(c::Matrix{Float64}, ext::Float64, ob::Union{Circle,Trefoil}, ns::Int, nd::Int, dt::Float64)
+    m = SharedArray{Float64}((ns * nd, 9))
+    prm = CShootParams(ns, nd, 0, ns, 0.0, Float64(pi), dt, TIME_STEPS, 0)
+    cob = Ref(c_obstacle(ob))
+    with_medium(c, ext) do med
+        check(ccall((:ray_shoot_to_exit, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ref{CObstacle}, Ref{CShootParams}, Ptr{Cdouble}, Int64,
+                     Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    context(), med, cob, prm, m, ns * nd, C_NULL, C_NULL, C_NULL))
+    end
+    m
+end
+
+# polylines [ray][point][x,y] -> one (npts x 2) matrix per ray
+function unpack_paths(path::Array{Float64,3}, npts::Vector{Int32}, max_pts::Int)
+    any(npts .> max_pts) && error("a ray produced $(maximum(npts)) points; raise max_pts (= $max_pts)")
+    [permutedims(path[:, 1:npts[k], k]) for k in 1:length(npts)]
+end
+
+# ---- Obstacle.jl:222 without PyPlot: the fixed-time (overshooting) trace of every row plus its polyline `res` ----
+function NonReflectionPlot(c::Matrix{Float64}, m::AbstractMatrix{Float64}, ext::Float64, dt::Float64; max_pts::Int = 4096)
+    num = size(m, 1)
+    mm = Matrix{Float64}(m)
+    X = Matrix{Float64}(undef, num, 4)
+    path = zeros(Float64, 2, max_pts, num)            # column-major [x,y | point | ray] = C's [ray][point][x,y]
+    npts = zeros(Int32, num)
+    with_medium(c, ext) do med
+        check(ccall((:ray_trace_paths, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cdouble, Cint, Cint, Ptr{Cdouble}, Ptr{Int32},
+                     Ptr{Cdouble}, Int64, Ptr{Int32}, Ptr{Int32}),
+                    context(), med, mm, num, max(num, 1), dt, TRACE_OVERSHOOT, max_pts, path, npts, X, max(num, 1), C_NULL, C_NULL))
+    end
+    unpack_paths(path, npts, max_pts)
+end
+
+# ---- Obstacle.jl:98 without PyPlot: m as the reference fills it (rows of rayIndex shot) and their polylines -----
+function ScatterRelationObstaclePlot(c::Analytic, ∇c, ob::Union{Circle,Trefoil}, ∇ob, ns::Int, nd::Int, dt::Float64,
+                                     rayIndex::AbstractVector{<:Integer}; max_pts::Int = 4096)
+    m = ScatterRelationObstacle(c, ∇c, ob, ∇ob, ns, nd, dt)
+    m[:, 5:9] .= 0.0
+    sel = Matrix{Float64}(m[rayIndex, :])
+    num = size(sel, 1)
+    path = zeros(Float64, 2, max_pts, num)
+    npts = zeros(Int32, num)
+    cob = Ref(c_obstacle(ob))
+    with_medium(c) do med
+        check(ccall((:ray_shoot_paths, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ref{CObstacle}, Cdouble, Int32, Int32, Ptr{Cdouble}, Int64, Int64, Int32,
+                     Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    context(), med, cob, dt, TIME_STEPS, 0, sel, num, max(num, 1), max_pts, path, npts, C_NULL, C_NULL, C_NULL))
+    end
+    m[rayIndex, :] = sel
+    m, unpack_paths(path, npts, max_pts)
+end
+
+# ---- Utility.jl:1-39 + ObstacleDemo.jl:48-67 on the device -------------------------------------------------------
+"returns (orthoIndex, lo, hi, arg): orthoIndex 1-based rows (ObstacleDemo.jl:48-49); lo / hi per source, 1-based as
+derivativeCheck returns them (Utility.jl:15-39); arg the aligned exit angles (nd x ns)"
+function classify_rays(m::AbstractMatrix{Float64}, ns::Int, nd::Int)
+    num = ns * nd
+    mm = Matrix{Float64}(m)
+    ortho = zeros(UInt8, num); arg = zeros(num); lo = zeros(Int32, ns); hi = zeros(Int32, ns)
+    check(ccall((:ray_classify, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Int64, Ptr{UInt8}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
+                context(), mm, ns, nd, max(num, 1), ortho, arg, lo, hi))
+    findall(!iszero, ortho), lo, hi, reshape(arg, nd, ns)
+end
+
+# ---- the device-resident Frechet matrix and the loop's passes over it (NonObstacle.jl:340-367) ---------------------
+mutable struct Frechet
+    h::Ptr{Cvoid}
+    med::Ptr{Cvoid}
+    nrows::Int; ncols::Int; nnz::Int
+end
+
+"ScatterForwardOperator with M left on the device: returns (F::Frechet, s).  close(F) releases it."
+function forward_operator_dev(c::Matrix{Float64}, m, ext::Float64, dt::Float64; droptol::Float64 = 1e-12)
+    num = size(m, 1); N = size(c, 1)
+    mm = Matrix{Float64}(m)
+    X = Matrix{Float64}(undef, num, 4)
+    med = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_medium_create_grid, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), context(), c, N, ext, med))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_forward_operator, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cdouble, Cdouble, Ptr{Cdouble}, Int64,
+                 Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                context(), med[], mm, num, max(num, 1), dt, droptol, X, max(num, 1), C_NULL, C_NULL, C_NULL, h))
+    nr = Ref{Int64}(0); nc = Ref{Int64}(0); nz = Ref{Int64}(0)
+    check(ccall((:ray_frechet_shape, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), h[], nr, nc, nz))
+    s = SharedArray{Float64}((num, 9))
+    s[:, 1:4] = m[:, 1:4]; s[:, 9] = m[:, 9]; s[:, 5:8] = X
+    Frechet(h[], med[], Int(nr[]), Int(nc[]), Int(nz[])), s
+end
+
+function Base.close(F::Frechet)
+    F.h != C_NULL && ccall((:ray_frechet_destroy, LIB), Cint, (Ptr{Cvoid},), F.h)
+    F.med != C_NULL && ccall((:ray_medium_destroy, LIB), Cint, (Ptr{Cvoid},), F.med)
+    F.h = C_NULL; F.med = C_NULL
+    nothing
+end
+
+maskptr(mask) = mask === nothing ? Ptr{UInt8}(C_NULL) : pointer(mask)
+
+"dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])   (NonObstacle.jl:340-342)"
+function dofs(F::Frechet, fidelity::Vector{Float64})
+    out = zeros(F.nrows ÷ 4)
+    check(ccall((:ray_frechet_dofs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), F.h, fidelity, out))
+    out
+end
+
+function matvec(F::Frechet, x::Vector{Float64})
+    y = zeros(F.nrows)
+    check(ccall((:ray_frechet_matvec, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), F.h, x, y))
+    y
+end
+
+"b = M[order,:]' * v[order] over all N^2 columns (NonObstacle.jl:354: take b[Idx]); mask::Vector{UInt8} per ray or nothing"
+function rmatvec(F::Frechet, v::Vector{Float64}, mask = nothing)
+    b = zeros(F.ncols)
+    GC.@preserve mask check(ccall((:ray_frechet_matvec_t, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Ptr{Cdouble}),
+                                  F.h, v, maskptr(mask), b))
+    b
+end
+
+"w = M[order,:]' * (M[order,:] * x): the action of MtM (NonObstacle.jl:353) without forming it"
+function normal_matvec(F::Frechet, x::Vector{Float64}, mask = nothing)
+    w = zeros(F.ncols)
+    GC.@preserve mask check(ccall((:ray_frechet_normal_matvec, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Ptr{Cdouble}),
+                                  F.h, x, maskptr(mask), w))
+    w
+end
+
+function normal_diag(F::Frechet, mask = nothing)
+    d = zeros(F.ncols)
+    GC.@preserve mask check(ccall((:ray_frechet_normal_diag, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Cdouble}),
+                                  F.h, maskptr(mask), d))
+    d
+end
+
+"NonObstacle.jl:359-367 in place on `fidelity`; returns the residual (0 on unselected rows)"
+function fidelity_update!(F::Frechet, correction::Vector{Float64}, mismatch::Vector{Float64}, fidelity::Vector{Float64},
+                          rejection::Float64, decay::Float64, mask = nothing)
+    residual = zeros(F.nrows)
+    GC.@preserve mask check(ccall((:ray_frechet_fidelity_update, LIB), Cint,
+                                  (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{UInt8}, Cdouble, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}),
+                                  F.h, correction, mismatch, maskptr(mask), rejection, decay, fidelity, residual))
+    residual
+end
+
+# ---- node-wide fan-out: what addprocs(3) / @sync @parallel / remotecall_wait give the reference's callers -----------
+# (NonObstacleDemo.jl:1; NonObstacle.jl:59,236-240).  One Julia process, every GPU of the node.
+mutable struct RayGroup
+    h::Ptr{Cvoid}
+    n::Int
+    rows::Int
+end
+
+function RayGroup(devices::Vector{<:Integer})
+    dev = Vector{Cint}(devices)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_group_create, LIB), Cint, (Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}), dev, length(dev), h))
+    RayGroup(h[], length(dev), 0)
+end
+
+function Base.close(g::RayGroup)
+    g.h != C_NULL && ccall((:ray_group_destroy, LIB), Cint, (Ptr{Cvoid},), g.h)
+    g.h = C_NULL
+    nothing
+end
+
+"ScatterRelation on a gridded medium over all GPUs of the group: member k shoots theta-block k"
+function ScatterRelation(g::RayGroup, c::Matrix{Float64}, ext::Float64, ns::Int, nd::Int, dt::Float64, dir = (0, pi))
+    N = size(c, 1)
+    m = SharedArray{Float64}((ns * nd, 9))
+    prm = CShootParams(ns, nd, 0, ns, Float64(dir[1]), Float64(dir[2]), dt, TIME_SECONDS, 0)
+    med = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_group_medium_create_grid, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), g.h, c, N, ext, med))
+    try
+        check(ccall((:ray_group_shoot_to_exit, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{CObstacle}, Ref{CShootParams}, Ptr{Cdouble}, Int64,
+                     Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                    g.h, med[], C_NULL, prm, m, ns * nd, C_NULL, C_NULL, C_NULL))
+    finally
+        ccall((:ray_group_medium_destroy, LIB), Cint, (Ptr{Cvoid},), med[])
+    end
+    g.rows = ns * nd
+    m
+end
+
+"the observation the group's misfit is taken against (rows as the last ScatterRelation(g, ...) laid them out)"
+function set_observation!(g::RayGroup, observation::AbstractMatrix{Float64})
+    o = Matrix{Float64}(observation)
+    check(ccall((:ray_group_set_observation, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64),
+                g.h, o, size(o, 1), max(size(o, 1), 1)))
+end
+
+"misfit of the slabs resident from the last ScatterRelation(g, ...): one RCCL all-reduce of the two sums"
+function misfit(g::RayGroup, perc_thresh::Float64 = 0.2)
+    out = zeros(2); mask = zeros(UInt8, g.rows); mism = zeros(4 * g.rows)
+    check(ccall((:ray_group_misfit, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{UInt8}, Cdouble, Ptr{Cdouble}),
+                g.h, out, mask, perc_thresh, mism))
+    mism, sqrt(out[1] / out[2]), mask
 end
 
 # ---- NonObstacle.jl:336,372; ObstacleDemo.jl:219-226 --------------------------------------------------------
