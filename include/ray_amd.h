@@ -29,6 +29,7 @@
  */
 #ifndef RAY_AMD_H
 #define RAY_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -86,6 +87,18 @@ int         ray_ctx_release_workspaces(ray_ctx *ctx);
 #define RAY_ARITH_EXACT 0
 #define RAY_ARITH_FUSED 1
 int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
+
+/* Options of the host-pointer entry points.
+ *   RAY_OPT_SKIP_INIT_COLUMNS  ray_shoot_to_exit copies back columns 5..9 only (the caller already holds the
+ *                              initial states or does not need them): 44 % fewer bytes over PCIe             */
+#define RAY_OPT_SKIP_INIT_COLUMNS 1
+int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
+/* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by
+ * ray_ctx_release_workspaces / ray_ctx_destroy) and copy to / from the caller's arrays.  From pageable memory
+ * those copies run at a fraction of the PCIe rate: a caller that keeps its m / s arrays alive across calls (the
+ * reference's SharedArrays live for the whole reconstruction, NonObstacle.jl:58,196) can page-lock them once. */
+int         ray_host_register(void *ptr, size_t bytes);
+int         ray_host_unregister(void *ptr);
 
 /* out[k] = linspace(a, b, n)[k+1] exactly as the library (and Julia's TwicePrecision ranges,
  * NonObstacle.jl:55-56,191) evaluates it: the correctly rounded a + k(b-a)/(n-1).  Host only;

@@ -78,6 +78,9 @@ class Context:
         ARITH_FUSED (default: multiply-adds contracted)."""
         _lib.check(self._lib.ray_ctx_set_arith(self.handle, int(arith)))
 
+    def set_option(self, option, value):
+        _lib.check(self._lib.ray_ctx_set_option(self.handle, int(option), int(value)))
+
     def enable_timing(self, on=True):
         _lib.check(self._lib.ray_ctx_enable_timing(self.handle, int(bool(on))))
 
@@ -99,6 +102,15 @@ def default_context():
     if _default_ctx is None:
         _default_ctx = Context(0)
     return _default_ctx
+
+
+def host_register(a):
+    """Page-lock a numpy array the caller keeps across calls (ray_host_register); host_unregister(a) undoes it."""
+    _lib.check(_lib.load().ray_host_register(_ptr(a), a.nbytes))
+
+
+def host_unregister(a):
+    _lib.check(_lib.load().ray_host_unregister(_ptr(a)))
 
 
 def device_count():

@@ -13,6 +13,7 @@ TIME_SECONDS, TIME_STEPS = 0, 1
 TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT = 0, 1
 ARITH_EXACT, ARITH_FUSED = 0, 1
 STREAM_OWN, STREAM_BORROWED = 0, 1
+OPT_SKIP_INIT_COLUMNS = 1
 
 
 class RayError(RuntimeError):
@@ -49,6 +50,9 @@ SIGNATURES = {
     "ray_ctx_synchronize": [_vp],
     "ray_ctx_release_workspaces": [_vp],
     "ray_ctx_set_arith": [_vp, C.c_int],
+    "ray_ctx_set_option": [_vp, C.c_int, C.c_int],
+    "ray_host_register": [_vp, C.c_size_t],
+    "ray_host_unregister": [_vp],
     "ray_medium_create_grid": [_vp, _vp, C.c_int, _f64, C.POINTER(_vp)],
     "ray_medium_update_grid": [_vp, _vp],
     "ray_medium_update_grid_dev": [_vp, _vp],

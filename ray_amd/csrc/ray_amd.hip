@@ -69,6 +69,16 @@ __global__ __launch_bounds__(256) void k_build_tables(const double *__restrict__
     }
 }
 
+#ifdef RAY_TIMELINE
+// instrumentation build only (scripts/timeline.py): start / end clock and hardware id of every workgroup of the
+// last k_shoot launch, to see how full the chip is over the launch
+__device__ unsigned long long g_ray_timeline[3 * 65536];
+#endif
+
+#ifndef RAY_ARC_ROT
+#define RAY_ARC_ROT(rank) (rank)
+#endif
+
 struct ShootArgs {
     MediumDev med;
     int ob_kind;
@@ -142,8 +152,9 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 // wavefront is a coherent fan: similar step counts (chord ~ 2 sin(phi)) and neighbouring cells.
 //  - the RK4 step is executed by ALL 64 lanes while any lane of the wavefront is alive: the
 //    gridded right-hand side fetches cell records wave-cooperatively (ray_device.h) and needs the
-//    wave converged.  A finished lane steps with dt = 0, which leaves its state bit-for-bit in
-//    place next to its still-running neighbours (no per-component select);
+//    wave converged.  Only the lanes that were live at the start of a step take its result (four
+//    exec-masked moves): a finished lane's state stays in place bit for bit, whatever its stages
+//    evaluated to (garbage states that overflow included);
 //  - all lanes of a wave start together, so elapsed time and step count are wave-uniform until a
 //    lane leaves: they are kept once per wave and latched by each lane at its exit;
 //  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
@@ -169,7 +180,11 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         const int nchunk = (a.nd + dmask) >> a.dshift;
         const int rank = (int)(blockIdx.x / (unsigned)a.ngroup);
         int gi = (int)(blockIdx.x - (unsigned)rank * (unsigned)a.ngroup);
-        if ((a.ngroup & 7) == 0) gi = (gi & 7) * (a.ngroup >> 3) + (gi >> 3);
+        // an XCD takes every 8th workgroup of the launch and nothing moves between XCDs afterwards: the arc it sweeps
+        // rotates from chunk to chunk, so that every XCD sees every part of the medium (arcs differ in ray length
+        // by 10-20 % in a non-symmetric medium; a fixed arc per XCD left half the chip idle for the last 15 %
+        // of the launch -- profiles/r2/timeline.md)
+        if ((a.ngroup & 7) == 0) gi = (((gi & 7) + RAY_ARC_ROT(rank)) & 7) * (a.ngroup >> 3) + (gi >> 3);
         const int mid = nchunk >> 1, hh = (rank + 1) >> 1;
         const int chunk = (rank & 1) ? mid - hh : mid + hh;
         const int lane = (int)(threadIdx.x & 63);
@@ -181,6 +196,14 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         valid = r < a.num;
     }
+#ifdef RAY_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_ray_timeline[3 * blockIdx.x] = wall_clock64();
+        g_ray_timeline[3 * blockIdx.x + 2] = hw;
+    }
+#endif
     GridAcc acc{};
     if (MED == kGrid) acc = grid_acc_setup<AR == kExact>(a.med.g);
     double X[4] = {0, 0, 1, 0};                             // harmless state for padding lanes
@@ -216,15 +239,17 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     // its output row (columns 5..8) until the deferred bisection picks it up: holding it in registers
     // would cost a wave per SIMD, and LDS is spent on record slots.
     const double dt = a.dt;
-    double dtl = valid ? dt : 0.0; // this lane's step: 0 once it has left (or is padding)
     double tw = 0, t = 0;          // tw: wave-uniform clock; t: this lane's, latched at its exit
     int it = 0, steps = 0;         // it: wave-uniform step count
     int nref = 0, rfl = 0;
     bool active = valid;
     // one back edge, one exit: wave-uniform condition; live lanes left at the cap get STEP_CAP below.
-    // lm = the live lanes (dtl != 0), balloted once per step.  The raw cell indices are max-ed into `o`
-    // over ALL steps and judged when the lane leaves (or at the cap): what a finished lane adds to its
-    // own `o` afterwards is never looked at.  A NaN position never leaves and is judged at the cap.
+    // lm = the live lanes, balloted once per step.  Every lane computes the step (the fetch needs the wave
+    // converged, and dt stays a scalar), but only the lanes that were live at its start TAKE it: a finished
+    // or padding lane keeps its latched state untouched, whatever its right-hand side evaluates to.
+    // The raw cell indices are max-ed into `o` over ALL steps and judged when the lane leaves (or at the
+    // cap): what a finished lane adds to its own `o` afterwards is never looked at.  A NaN position never
+    // leaves and is judged at the cap.
     unsigned long long lm = __builtin_amdgcn_ballot_w64(active);
     OobMax o = 0;
     RecState rs;
@@ -232,9 +257,10 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     // the reflection point R whose value ended the bisection (:79): evaluated once, carried
     double obv = (OB != kObNone) ? ob_val<OB>(a, X[0], X[1]) : 0.0;
     if (lm != 0 && a.max_steps > 0) do {
+        const bool was = active;
         if (OB != kObNone) { if (active && obv > 0) rfl = 0; }                             // Obstacle.jl:28-30
         double Xn[4];
-        rk4<MED, AR, 0>(a.med, acc, X, Xn, dtl, lm, o, rs);
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, dt, lm, o, rs);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
             if (s >= 1.0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) a.m[r + (4 + k) * a.ld] = X[k];   // the pre-step state (`prev`)
-                t = tw; steps = it; dtl = 0.0;
+                t = tw; steps = it;
                 st |= kStExited; active = false;
                 if (MED == kGrid) oob |= oob_hit(a.med.g, o);
             } else if (OB != kObNone) {
@@ -277,9 +303,11 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
             }
             if (PATH && active) put(Xn[0], Xn[1]);          // res = [res X[1:2]]      Obstacle.jl:211
         }
+        if (was) {                                          // exec-masked: frozen lanes keep their state bit for bit
 #pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = Xn[k];
-        lm = __builtin_amdgcn_ballot_w64(dtl != 0.0);
+            for (int k = 0; k < 4; ++k) asm volatile("v_mov_b64 %0, %1" : "+v"(X[k]) : "v"(Xn[k]));
+        }
+        lm = __builtin_amdgcn_ballot_w64(active);
     } while (lm != 0 && it < a.max_steps);
     if (active) {
         st |= kStStepCap; t = tw; steps = it;
@@ -328,6 +356,10 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     }
     const unsigned wsum = wave_sum((unsigned)steps);
     if ((threadIdx.x & 63) == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+#ifdef RAY_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_ray_timeline[3 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 struct TraceArgs {
@@ -386,6 +418,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         }
         double Xn[4];
         OobMax o = 0;
+        const bool was = active;
         rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o, rs);
         ++it;
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
@@ -405,8 +438,10 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
             if (PATH) put(Xn[0], Xn[1]);                    // res = [res X[1:2]]      Obstacle.jl:266
             active = t < T;
         }
+        if (was) {                                          // exec-masked: a finished lane keeps its end state bit for bit
 #pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = Xn[k];
+            for (int k = 0; k < 4; ++k) asm volatile("v_mov_b64 %0, %1" : "+v"(X[k]) : "v"(Xn[k]));
+        }
     } while (__builtin_amdgcn_ballot_w64(active) != 0 && it < a.max_steps);
     if (PATH && valid && a.npts) a.npts[r] = np;
     if (active) st |= kStStepCap;
@@ -586,9 +621,10 @@ struct ray_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     // grow-only device workspaces reused across calls (the Frechet stencil slab: a reconstruction loop
     // calls ScatterForwardOperator every iteration with the same sizes)
-    static constexpr int kWs = 12;
+    static constexpr int kWs = 24;             // 0..11 the Frechet path, 12..23 staging of the host-pointer entry points
     void *ws[kWs] = {};
     size_t ws_cap[kWs] = {};
+    bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
     // one retired CSR triple (ray_frechet_destroy parks it here, the next ray_forward_operator takes it
     // back if it is large enough): the loop frees M and builds the next one every iteration
     void *csr_pool[3] = {};
@@ -1177,8 +1213,14 @@ static int copy_cols_d2h(ray_ctx *ctx, double *dst, int64_t ldd, const double *s
     return RAY_OK;
 }
 
+// staging slots of the host-pointer entry points (grow-only, kept by the context: a caller that shoots the same
+// sweep every iteration -- a blocking Julia ccall -- allocates on its first call only)
+enum { kWsM = 12, kWsSt = 13, kWsNs = 14, kWsNr = 15, kWsX = 16, kWsObs = 17, kWsOut = 18, kWsMask = 19, kWsMis = 20,
+       kWsPath = 21, kWsNpts = 22, kWsAux = 23 };
+
 struct RayOutBufs {
-    DevBuf st, ns, nr;
+    WsBuf st, ns, nr;
+    explicit RayOutBufs(ray_ctx *c) : st(c, kWsSt), ns(c, kWsNs), nr(c, kWsNr) {}
     int alloc(int64_t num) {
         HIPCHK(st.alloc(sizeof(int32_t) * (size_t)num));
         HIPCHK(ns.alloc(sizeof(int32_t) * (size_t)num));
@@ -1204,13 +1246,14 @@ int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *o
     const int64_t num = (int64_t)(prm->src_end - prm->src_begin) * prm->nd;
     if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
     if (num == 0) return RAY_OK;
-    DevBuf dm;
-    RayOutBufs ob_;
+    WsBuf dm(ctx, kWsM);
+    RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     if ((rc = ob_.alloc(num))) return rc;
     rc = shoot_to_exit_impl(ctx, med, ob, prm, dm.as<double>(), num, ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, 0, 9))) return rc;
+    const int c0 = ctx->skip_init_cols ? 4 : 0;             // RAY_OPT_SKIP_INIT_COLUMNS: columns 5..9 only
+    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, c0, 9 - c0))) return rc;
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;
@@ -1242,8 +1285,8 @@ int ray_shoot_states(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob
     if (rc) return rc;
     if (!m_host || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad m / num / ld");
     if (num == 0) return RAY_OK;
-    DevBuf dm;
-    RayOutBufs ob_;
+    WsBuf dm(ctx, kWsM);
+    RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     if ((rc = ob_.alloc(num))) return rc;
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
@@ -1269,8 +1312,8 @@ int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
     if (time_unit != RAY_TIME_SECONDS && time_unit != RAY_TIME_STEPS) return fail(RAY_ERR_INVALID, "bad time_unit");
     if (num == 0) return RAY_OK;
     const size_t pbytes = sizeof(double) * 2 * (size_t)max_pts * (size_t)num;
-    DevBuf dm, dpath, dnp;
-    RayOutBufs ob_;
+    WsBuf dm(ctx, kWsM), dpath(ctx, kWsPath), dnp(ctx, kWsNpts);
+    RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dpath.alloc(pbytes));
     HIPCHK(dnp.alloc(sizeof(int32_t) * (size_t)num));
@@ -1344,8 +1387,8 @@ int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_ho
     if (rc) return rc;
     if (!m_host || !X_host || num < 0 || ld < num || ldx < num) return fail(RAY_ERR_INVALID, "bad m / X / num / ld");
     if (num == 0) return RAY_OK;
-    DevBuf dm, dX;
-    RayOutBufs ob_;
+    WsBuf dm(ctx, kWsM), dX(ctx, kWsX);
+    RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
     if ((rc = ob_.alloc(num))) return rc;
@@ -1371,8 +1414,8 @@ int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, i
         return fail(RAY_ERR_INVALID, "bad m / X / path / npts / num / ld / max_pts");
     if (num == 0) return RAY_OK;
     const size_t pbytes = sizeof(double) * 2 * (size_t)max_pts * (size_t)num;
-    DevBuf dm, dX, dpath, dnp;
-    RayOutBufs ob_;
+    WsBuf dm(ctx, kWsM), dX(ctx, kWsX), dpath(ctx, kWsPath), dnp(ctx, kWsNpts);
+    RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
     HIPCHK(dpath.alloc(pbytes));
@@ -1501,7 +1544,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
         return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the stencil slab does not fit in device memory (sum of T/dt too large); split the rays");
     WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), duoff(ctx, 8),
           ducols(ctx, 9), duvals(ctx, 10), drowcnt(ctx, 11);
-    RayOutBufs ob_;
+    RayOutBufs ob_(ctx);
     void *pkeys = nullptr, *pvals = nullptr;
     HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * sizeof(int64_t), &pkeys));
     HIPCHK(ctx_workspace(ctx, 1, (slots ? slots : 1) * 4 * sizeof(double), &pvals));
@@ -1948,6 +1991,15 @@ int ray_classify(ray_ctx *ctx, const double *m_host, int64_t ns, int64_t nd, int
     return RAY_OK;
 }
 
+#ifdef RAY_TIMELINE
+int ray_debug_timeline(unsigned long long *out, int nblocks)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return RAY_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_timeline), sizeof(unsigned long long) * 3 * (size_t)nblocks) != hipSuccess) return RAY_ERR_HIP;
+    return RAY_OK;
+}
+#endif
+
 #ifdef RAY_STATS
 // instrumentation build only (scripts/): look-up statistics of the cell cache since the last call
 int ray_debug_stats(unsigned long long out[12])
@@ -2002,7 +2054,7 @@ int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64
     int rc = use(ctx);
     if (rc) return rc;
     if (!m_host || !obs_host || !out || num < 0 || ld < num) return fail(RAY_ERR_INVALID, "bad misfit arguments");
-    DevBuf dm, dobs, dout, dmask, dmis;
+    WsBuf dm(ctx, kWsM), dobs(ctx, kWsObs), dout(ctx, kWsOut), dmask(ctx, kWsMask), dmis(ctx, kWsMis);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dobs.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dout.alloc(sizeof(double) * 2));
@@ -2020,6 +2072,40 @@ int ray_misfit(ray_ctx *ctx, const double *m_host, const double *obs_host, int64
     if (mismatch && num) HIPCHK(hipMemcpyAsync(mismatch, dmis.p, sizeof(double) * 4 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;
+}
+
+int ray_ctx_set_option(ray_ctx *ctx, int option, int value)
+{
+    if (!ctx) return fail(RAY_ERR_INVALID, "null context");
+    if (option == RAY_OPT_SKIP_INIT_COLUMNS) { ctx->skip_init_cols = value != 0; return RAY_OK; }
+    return fail(RAY_ERR_INVALID, "unknown option");
+}
+
+// page-lock a caller-owned host array so that the host-pointer entry points copy at the full PCIe rate.
+// The runtime wants whole pages: the page-aligned span around [ptr, ptr + bytes) is what gets registered
+// (remembered per ptr for ray_host_unregister).
+static std::vector<std::pair<void *, void *>> g_registered;      // (caller's ptr, registered base)
+int ray_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(RAY_ERR_INVALID, "ray_host_register: null pointer / zero size");
+    const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(ptr) & ~(page - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + bytes + page - 1) & ~(page - 1);
+    HIPCHK(hipHostRegister(reinterpret_cast<void *>(lo), hi - lo, hipHostRegisterDefault));
+    g_registered.emplace_back(ptr, reinterpret_cast<void *>(lo));
+    return RAY_OK;
+}
+
+int ray_host_unregister(void *ptr)
+{
+    for (size_t k = 0; k < g_registered.size(); ++k)
+        if (g_registered[k].first == ptr) {
+            void *base = g_registered[k].second;
+            g_registered[k] = g_registered.back();
+            g_registered.pop_back();
+            HIPCHK(hipHostUnregister(base));
+            return RAY_OK;
+        }
+    return fail(RAY_ERR_INVALID, "ray_host_unregister: not a pointer ray_host_register was given");
 }
 
 int ray_ctx_set_arith(ray_ctx *ctx, int arith)

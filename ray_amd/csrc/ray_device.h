@@ -8,6 +8,8 @@
 // division sequence (validated against `/` on 2.4e9 operands, tests/test_host_math.py):
 //   - x / 6.0         (RK4 combination, NonObstacle.jl:76,171; Obstacle.jl:38,317)
 //   - (x - p[1]) / h  (cell index,      NonObstacle.jl:33-34)
+// One bit pattern differs from IEEE division: a zero dividend of negative sign gives +0.0 (the residual
+// fma(-b, -0, -0) is +0); equal in value, and a zero momentum component stays zero either way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -410,9 +412,10 @@ __device__ __forceinline__ void h_from_record(const double X[4], double dx, doub
 // stage 2, the next step's stage 1 ~dt^2 from stage 4 -- so stages 2 and 4 FETCH, stages 3 and 1 LOOKUP.
 enum RecMode { kFetch = 0, kLookup = 1 };
 
-// `lm`: ballot of the lanes that still integrate (dt != 0), taken once per step by the caller.  A finished lane sits frozen at its exit point, far
-// from the fan, and would add a run of its own to every fetch until the whole wave is done: it looks
-// up the first live lane's cell instead.  What it computes from that record is multiplied by dt = 0.
+// `lm`: ballot of the lanes that still integrate, taken once per step by the caller.  A finished lane sits
+// frozen at its exit point, far from the fan, and would add a run of its own to every fetch until the whole
+// wave is done: it looks up the first live lane's cell instead.  What it computes from that record is dropped
+// (the callers take a step's result for live lanes only).
 template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
                                          unsigned long long lm, RecState &rs)
@@ -545,7 +548,7 @@ __device__ __forceinline__ double fma_vop3(double a, double b, double c)
     return d;
 }
 
-// One classical RK4 step X -> Xn with step dt (dt == 0 leaves Xn == X: how finished lanes idle).
+// One classical RK4 step X -> Xn with step dt (the callers keep X for lanes that were not live).
 // FORM 0 = a6/a7: k = H*dt; X + k1/2; (k1+2k2+2k3+k4)/6.0         NonObstacle.jl:72-76
 // FORM 1 = a8/a9: k = H;    X + k/2*dt; (k1+2k2+2k3+k4)*dt/6.0    NonObstacle.jl:161-164,171
 // kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)

@@ -368,10 +368,12 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         rho_stage<1>(Jm, R, rho, accr, R, dtl);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
         const double dt6 = dtl * 0.16666666666666666;
+        if (active) {                          // a finished lane keeps (X, rho) untouched whatever its stages evaluated to
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            X[k] = (AR == kFused) ? __builtin_fma(accx[k] + H[k], dt6, X[k]) : X[k] + div6((accx[k] + H[k]) * dtl);
-        rho_stage<2>(Jm, R, rho, accr, rho, dt6);
+            for (int k = 0; k < 4; ++k)
+                X[k] = (AR == kFused) ? __builtin_fma(accx[k] + H[k], dt6, X[k]) : X[k] + div6((accx[k] + H[k]) * dtl);
+            rho_stage<2>(Jm, R, rho, accr, rho, dt6);
+        }
         ++it;
         wp = 0.0;
         if (active) {
