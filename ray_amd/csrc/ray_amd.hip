@@ -602,8 +602,10 @@ static int fail(int code, const std::string &msg)
 #define HIPCHK(expr)                                                                           \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();     /* reported here: do not leave it for the next launch's check */ \
             return fail(RAY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+        }                                                                                      \
     } while (0)
 
 struct InitTables;
