@@ -64,9 +64,14 @@ def main():
         ctx.enable_timing(False)
         ms = c["kernel_ms"] / max(c["launches"], 1)
         steps = c["ray_steps"] / max(c["launches"], 1)
+        # live lanes: a wave (2 sources x 32 directions) steps until its last lane has left
+        live = None
+        if "shoot" in name and ns % 2 == 0 and nd % 32 == 0:
+            w = nst.view(ns // 2, 2, nd // 32, 32).to(torch.int64)
+            live = float(w.sum().item()) / float(64 * w.amax(dim=(1, 3)).sum().item())
         print(json.dumps({"workload": name, "arith": arith, "rays": num, "kernel_ms": round(ms, 3),
                           "ray_steps": int(steps), "ray_steps_per_s": steps / (ms * 1e-3),
-                          "rays_per_s": num / (ms * 1e-3), "steps_per_ray": steps / num,
+                          "rays_per_s": num / (ms * 1e-3), "steps_per_ray": steps / num, "live_lane_fraction": live,
                           "reflections": int(nrf.sum().item()) if "obstacle" in name else 0,
                           "not_exited": int((st & 1).eq(0).sum().item()) if "trace" not in name else 0}), flush=True)
 
