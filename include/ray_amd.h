@@ -199,9 +199,13 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
  *   |v| <= droptol removed (the reference passes 1e-12; droptol < 0 keeps every stencil entry).
  * A Julia caller gets the reference's SparseMatrixCSC with
  *   copy(transpose(SparseMatrixCSC(N^2, 4num, indptr .+ 1, indices .+ 1, data)))  (julia/RayAMD.jl).
- * The per-step stencil contributions pass through a device slab (480 B per ray-step); when that would
- * exceed a quarter of the free memory (or 16 GB) the rays go through in chunks and the CSR pieces
- * are concatenated -- the result is identical.
+ * The trajectory nodes pass through a device slab (one 128-byte record per ray-step plus 52 B of sort
+ * hand-over); when that would exceed a quarter of the free memory (or 16 GB) the rays go through in
+ * chunks and the pieces are concatenated -- the result is identical.
+ * On the device M lives as BLOCK ROWS -- per ray its distinct nodes, each with the column index and the
+ * values of the ray's four matrix rows (36 B per node instead of 48 B of CSR; droptol applied by the
+ * readers) -- which is what the loop passes below read; the CSR arrays are made from them when
+ * ray_frechet_export_csr / ray_frechet_csr_dev first ask.
  * Limits: 4*num < 2^31; at most 1364 steps per ray (T/dt).  Parity is by tolerance: the reference
  * goes through LAPACK inv / BLAS gemm for rho and Phi.                                           */
 typedef struct ray_frechet ray_frechet;
@@ -211,9 +215,15 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
 int ray_frechet_shape(ray_frechet *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
 /* indptr: 4num + 1, indices / data: nnz (host buffers) */
 int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, double *data);
-/* the same three arrays where they live in HBM (valid until ray_frechet_destroy) */
+/* the same three arrays in HBM (valid until ray_frechet_destroy; indices / data are converted on the
+ * context's stream by the first call that asks for them: pass NULL for both to get indptr alone) */
 int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data);
-/* Waits for the context's stream, then releases the handle.  Its three CSR arrays are parked on the
+/* The block rows where they live in HBM (no counterpart in the reference, whose M is a host CSC): ray j owns
+ * entries uoff[j] .. uoff[j+1] (uoff: num + 1); entry u is node ucols[u] (sorted within a ray) with
+ * M[4j + r, ucols[u]] = uvals[4u + r], r = 0..3, kept when |value| > droptol (all when droptol < 0).  */
+int ray_frechet_block_rows_dev(ray_frechet *f, int64_t *n_entries, const int64_t **uoff, const int32_t **ucols,
+                               const double **uvals);
+/* Waits for the context's stream, then releases the handle.  Its device arrays are parked on the
  * context (the largest of each kind) and handed to the next ray_forward_operator that fits in them, and
  * the operator's intermediates live in grow-only workspaces of the context: a reconstruction loop that
  * builds M every iteration (NonObstacle.jl:331-333) allocates nothing after the first one.  All of it is
@@ -222,7 +232,7 @@ int ray_frechet_destroy(ray_frechet *f);
 
 /* ---- passes of the reconstruction loop over M (NonObstacle.jl:340-367; SURVEY.md section 8f NEXT-2) ----
  * The normal-equation solve A\b (CHOLMOD, :353-356) stays with the caller; these are the O(nnz)
- * passes around it, run on the device CSR.  Vector lengths: fidelity / x / b = N^2 (node order
+ * passes around it, run on the device block rows.  Vector lengths: fidelity / x / b = N^2 (node order
  * i + j*N), v / mismatch / y / residual = 4 num (ray-major, like `mismatch` at :336), dofs / ray_mask =
  * num.  ray_mask[j] != 0 selects the four rows of ray j (the reference's `order`, :345-349; NULL = all).
  *   dofs[j]   = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])                     (:340-342)

@@ -525,6 +525,13 @@ class FrechetMatrix:
         _lib.check(self.ctx._lib.ray_frechet_csr_dev(self.handle, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def block_rows_dev(self):
+        """(n_entries, uoff, ucols, uvals) of the device-resident block rows: ray j owns entries uoff[j]..uoff[j+1],
+        entry u is node ucols[u] with the values uvals[4u:4u+4] of matrix rows 4j..4j+3 (before droptol)."""
+        n, a, b, c = C.c_int64(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self.ctx._lib.ray_frechet_block_rows_dev(self.handle, C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
+        return n.value, a.value, b.value, c.value
+
     # -- the reconstruction loop's passes over M (NonObstacle.jl:340-367), on the device -----------
     def _vec(self, a, n, dtype=np.float64):
         a = np.ascontiguousarray(a, dtype=dtype).reshape(-1)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "ray_frechet_shape": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "ray_frechet_export_csr": [_vp, _vp, _vp, _vp],
     "ray_frechet_csr_dev": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "ray_frechet_block_rows_dev": [_vp, C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ray_frechet_destroy": [_vp],
     "ray_frechet_dofs": [_vp, _vp, _vp],
     "ray_frechet_dofs_dev": [_vp, _vp, _vp],

@@ -627,10 +627,11 @@ struct ray_ctx {
     void *ws[kWs] = {};
     size_t ws_cap[kWs] = {};
     bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
-    // one retired CSR triple (ray_frechet_destroy parks it here, the next ray_forward_operator takes it
-    // back if it is large enough): the loop frees M and builds the next one every iteration
-    void *csr_pool[3] = {};
-    size_t csr_cap[3] = {};
+    // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
+    // takes them back if they are large enough): the loop frees M and builds the next one every iteration
+    static constexpr int kPool = 7;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows)
+    void *csr_pool[kPool] = {};
+    size_t csr_cap[kPool] = {};
     // handles created on this context and not yet destroyed: ray_ctx_destroy releases their device memory
     // and detaches them, so that destroying a handle after its context is harmless (only the struct is left)
     std::vector<struct ray_medium *> media;
@@ -857,7 +858,7 @@ int ray_ctx_destroy(ray_ctx *ctx)
     if (ctx->d_steps) (void)hipFree(ctx->d_steps);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     for (int k = 0; k < ray_ctx::kWs; ++k) if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
-    for (int k = 0; k < 3; ++k) if (ctx->csr_pool[k]) (void)hipFree(ctx->csr_pool[k]);
+    for (int k = 0; k < ray_ctx::kPool; ++k) if (ctx->csr_pool[k]) (void)hipFree(ctx->csr_pool[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RAY_OK;
@@ -891,7 +892,7 @@ int ray_ctx_release_workspaces(ray_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < ray_ctx::kWs; ++k)
         if (ctx->ws[k]) { (void)hipFree(ctx->ws[k]); ctx->ws[k] = nullptr; ctx->ws_cap[k] = 0; }
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < ray_ctx::kPool; ++k)
         if (ctx->csr_pool[k]) { (void)hipFree(ctx->csr_pool[k]); ctx->csr_pool[k] = nullptr; ctx->csr_cap[k] = 0; }
     return RAY_OK;
 }
@@ -1438,37 +1439,49 @@ int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, i
     return RAY_OK;
 }
 
-// ---- complete forward operator: X, rho, Frechet matrix as device CSR (NEXT-1) ------------------------
+// ---- complete forward operator: X, rho, Frechet matrix as device block rows (NEXT-1) -------------------
+enum { kFmIndptr = 0, kFmIndices, kFmData, kFmUoff, kFmUcols, kFmUvals, kFmRowcnt, kFmArrays };
+static_assert(kFmArrays == ray_ctx::kPool, "pool slots");
 struct ray_frechet {
     ray_ctx *ctx = nullptr;
-    int64_t num = 0, nnz = 0;
+    int64_t num = 0, nnz = 0, U = 0;    // rays, entries that survive droptol, distinct (ray, node) pairs
     int N = 0;
-    int64_t *d_indptr = nullptr;        // 4 num + 1
-    int32_t *d_indices = nullptr;       // nnz, sorted within a row
-    double *d_data = nullptr;           // nnz
-    size_t cap[3] = {0, 0, 0};          // bytes behind the three arrays
+    double droptol = -1;
+    // device arrays, see kFm*: [indptr 4 num + 1 | indices nnz | data nnz] (indices / data only once an export
+    // asked for them) and the block rows [uoff num + 1 | ucols U | uvals 4 U | rowcnt 4 num]
+    void *arr[kFmArrays] = {};
+    size_t cap[kFmArrays] = {};         // bytes behind them
+    bool csr_built = false;
+    int64_t *indptr() { return static_cast<int64_t *>(arr[kFmIndptr]); }
+    int32_t *indices() { return static_cast<int32_t *>(arr[kFmIndices]); }
+    double *data() { return static_cast<double *>(arr[kFmData]); }
+    int64_t *uoff() { return static_cast<int64_t *>(arr[kFmUoff]); }
+    int32_t *ucols() { return static_cast<int32_t *>(arr[kFmUcols]); }
+    double *uvals() { return static_cast<double *>(arr[kFmUvals]); }
+    int32_t *rowcnt() { return static_cast<int32_t *>(arr[kFmRowcnt]); }
+    BlockRows rows() { return BlockRows{uoff(), ucols(), uvals(), num, droptol}; }
 };
 
-// the three CSR arrays of f (sizes known): parked triple of the context or fresh memory
+// array `which` of f (size known): the context's parked one when it fits, else fresh memory
 static hipError_t frechet_alloc(ray_frechet *f, int which, size_t bytes)
 {
+    if (f->arr[which] && f->cap[which] >= bytes) return hipSuccess;
+    if (f->arr[which]) { (void)hipFree(f->arr[which]); f->arr[which] = nullptr; f->cap[which] = 0; }
     void *p = nullptr;
     size_t have = f->ctx->csr_pool[which] && f->ctx->csr_cap[which] >= bytes ? f->ctx->csr_cap[which] : (bytes ? bytes : 8);
     hipError_t e = csr_take(f->ctx, which, bytes, &p);
     if (e != hipSuccess) return e;
     f->cap[which] = have;
-    if (which == 0) f->d_indptr = static_cast<int64_t *>(p);
-    else if (which == 1) f->d_indices = static_cast<int32_t *>(p);
-    else f->d_data = static_cast<double *>(p);
+    f->arr[which] = p;
     return hipSuccess;
 }
 
 static void detach_frechet(ray_frechet *f)
 {
-    if (f->d_indptr) (void)hipFree(f->d_indptr);
-    if (f->d_indices) (void)hipFree(f->d_indices);
-    if (f->d_data) (void)hipFree(f->d_data);
-    f->d_indptr = nullptr; f->d_indices = nullptr; f->d_data = nullptr;
+    for (int k = 0; k < kFmArrays; ++k) {
+        if (f->arr[k]) (void)hipFree(f->arr[k]);
+        f->arr[k] = nullptr;
+    }
     f->ctx = nullptr;
 }
 
@@ -1476,19 +1489,18 @@ int ray_frechet_destroy(ray_frechet *f)
 {
     if (!f) return RAY_OK;
     if (f->ctx) forget(f->ctx->frechets, f);
-    void *arr[3] = {f->d_indptr, f->d_indices, f->d_data};
     if (f->ctx) {
         (void)hipSetDevice(f->ctx->device);
         (void)hipStreamSynchronize(f->ctx->stream);             // nothing of this handle is in flight after this
     }
-    for (int k = 0; k < 3; ++k) {
-        if (!arr[k]) continue;
+    for (int k = 0; k < kFmArrays; ++k) {
+        if (!f->arr[k]) continue;
         // park the larger of (this array, what is parked); free the other
         if (f->ctx && f->cap[k] > f->ctx->csr_cap[k]) {
             if (f->ctx->csr_pool[k]) (void)hipFree(f->ctx->csr_pool[k]);
-            f->ctx->csr_pool[k] = arr[k];
+            f->ctx->csr_pool[k] = f->arr[k];
             f->ctx->csr_cap[k] = f->cap[k];
-        } else (void)hipFree(arr[k]);
+        } else (void)hipFree(f->arr[k]);
     }
     delete f;
     return RAY_OK;
@@ -1535,30 +1547,30 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
         cap[(size_t)w] = (int32_t)n;
         if ((int)n > cap_max) cap_max = (int)n;
         wave_base[(size_t)w] = rows;
-        rows += frechet_entries((int)n);
+        rows += frechet_rows((int)n);
     }
     if (frechet_entries(cap_max) > kMergeMaxEntries)
         return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator: more than 1364 steps per ray (T/dt); the per-ray merge holds 16384 stencil entries");
-    const size_t slots = (size_t)rows * 64;
+    const size_t slots = (size_t)rows * 64;                  // trajectory records of this call
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (slots * 40 * 2 + (size_t)num * 512 > free_b)
-        return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the stencil slab does not fit in device memory (sum of T/dt too large); split the rays");
-    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), duoff(ctx, 8),
-          ducols(ctx, 9), duvals(ctx, 10), drowcnt(ctx, 11);
+    if (slots * (kTrajBytesPerRow + 12 * 36) + (size_t)num * 512 > free_b + ctx->ws_cap[0] + ctx->ws_cap[1] + ctx->ws_cap[9])
+        return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the trajectory slab does not fit in device memory (sum of T/dt too large); split the rays");
+    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7);
     RayOutBufs ob_(ctx);
-    void *pkeys = nullptr, *pvals = nullptr;
-    HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * sizeof(int64_t), &pkeys));
-    HIPCHK(ctx_workspace(ctx, 1, (slots ? slots : 1) * 4 * sizeof(double), &pvals));
-    BorrowedBuf dkeys{pkeys}, dvals{pvals};
+    void *ptraj = nullptr, *psrt = nullptr, *pcells = nullptr;
+    HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * kTrajDoubles * sizeof(double), &ptraj));
+    HIPCHK(ctx_workspace(ctx, 1, (slots ? slots : 1) * kFrSlotsPerCall * sizeof(uint32_t), &psrt));
+    HIPCHK(ctx_workspace(ctx, 9, (slots ? slots : 1) * sizeof(int32_t), &pcells));
+    BorrowedBuf dtraj{ptraj}, dsrt{psrt}, dcells{pcells};
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     HIPCHK(dX.alloc(sizeof(double) * 4 * (size_t)num));
     HIPCHK(drho.alloc(sizeof(double) * 16 * (size_t)num));
     HIPCHK(dbase.alloc(sizeof(int64_t) * (size_t)nwave));
     HIPCHK(dcap.alloc(sizeof(int32_t) * (size_t)nwave));
     HIPCHK(ducnt.alloc(sizeof(int32_t) * (size_t)num));
-    HIPCHK(duoff.alloc(sizeof(int64_t) * (size_t)(num + 1)));
-    HIPCHK(drowcnt.alloc(sizeof(int32_t) * 4 * (size_t)num));
+    HIPCHK(frechet_alloc(f, kFmUoff, sizeof(int64_t) * (size_t)(num + 1)));
+    HIPCHK(frechet_alloc(f, kFmRowcnt, sizeof(int32_t) * 4 * (size_t)num));
     int rc;
     if ((rc = ob_.alloc(num)) || (rc = ensure_hess(med))) return rc;
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
@@ -1572,7 +1584,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
     a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>();
-    a.keys = dkeys.as<int64_t>(); a.vals = dvals.as<double>();
+    a.traj = dtraj.as<double>(); a.cells = dcells.as<int32_t>();
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
     a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
     a.step_counter = ctx->d_steps;
@@ -1593,32 +1605,30 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     const bool narrow_key = !env_wide && eshift < 32 && (uint64_t)med->N * (uint64_t)med->N < (1ull << (32 - eshift)) - 1;
     const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8);
     if (narrow_key) {
-        if (sort_lds > 64 * 1024)
+        if (sort_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<256, uint32_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
-                           dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift);
+        hipLaunchKernelGGL((k_merge_sort<256, uint32_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
+                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     } else {
-        if (sort_lds > 64 * 1024)
+        if (sort_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<256, uint64_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dkeys.as<int64_t>(),
-                           dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift);
+        hipLaunchKernelGGL((k_merge_sort<256, uint64_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
+                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     }
     HIPCHK(hipGetLastError());
-    int64_t U = 0;
-    if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, duoff.as<int64_t>(), &U))) return rc;
-    HIPCHK(ducols.alloc(sizeof(int32_t) * (size_t)(U ? U : 1)));
-    HIPCHK(duvals.alloc(sizeof(double) * 4 * (size_t)(U ? U : 1)));
-    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, dkeys.as<int64_t>(), dvals.as<double>(),
-                       dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), drho.as<double>(), duoff.as<int64_t>(), droptol,
-                       ducols.as<int32_t>(), duvals.as<double>(), drowcnt.as<int32_t>());
+    if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, f->uoff(), &f->U))) return rc;
+    HIPCHK(frechet_alloc(f, kFmUcols, sizeof(int32_t) * (size_t)(f->U ? f->U : 1)));
+    HIPCHK(frechet_alloc(f, kFmUvals, sizeof(double) * 4 * (size_t)(f->U ? f->U : 1)));
+    // the ray's records sit in LDS during the merge when they fit (48 KiB = 384 rows; RAY_FRECHET_LDS_ROWS for the tests)
+    const char *env_rows = getenv("RAY_FRECHET_LDS_ROWS");
+    int lds_rows = std::min(frechet_rows(cap_max), 384);
+    if (env_rows) lds_rows = std::max(0, std::min(lds_rows, atoi(env_rows)));
+    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)num), dim3(256), (size_t)lds_rows * kTrajDoubles * sizeof(double), ctx->stream,
+                       dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(),
+                       drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, f->ucols(), f->uvals(), f->rowcnt());
     HIPCHK(hipGetLastError());
-    HIPCHK(frechet_alloc(f, 0, sizeof(int64_t) * (size_t)(4 * num + 1)));
-    if ((rc = scan_counts(ctx, drowcnt.as<int32_t>(), 4 * num, f->d_indptr, &f->nnz))) return rc;
-    HIPCHK(frechet_alloc(f, 1, sizeof(int32_t) * (size_t)(f->nnz ? f->nnz : 1)));
-    HIPCHK(frechet_alloc(f, 2, sizeof(double) * (size_t)(f->nnz ? f->nnz : 1)));
-    hipLaunchKernelGGL(k_csr_emit, dim3((unsigned)num), dim3(256), 0, ctx->stream, ducols.as<int32_t>(), duvals.as<double>(),
-                       duoff.as<int64_t>(), f->d_indptr, droptol, f->d_indices, f->d_data);
-    HIPCHK(hipGetLastError());
+    HIPCHK(frechet_alloc(f, kFmIndptr, sizeof(int64_t) * (size_t)(4 * num + 1)));
+    if ((rc = scan_counts(ctx, f->rowcnt(), 4 * num, f->indptr(), &f->nnz))) return rc;
     span.end();
     ctx->rays += (uint64_t)num;
     ctx->launches += 1;
@@ -1626,6 +1636,20 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if (rho_host) HIPCHK(hipMemcpyAsync(rho_host, drho.p, sizeof(double) * 16 * (size_t)num, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RAY_OK;
+}
+
+// indices / data of the CSR form, built from the block rows when an export first asks for them
+static int ensure_csr(ray_frechet *f)
+{
+    if (f->csr_built || f->num == 0) return RAY_OK;
+    ray_ctx *ctx = f->ctx;
+    HIPCHK(frechet_alloc(f, kFmIndices, sizeof(int32_t) * (size_t)(f->nnz ? f->nnz : 1)));
+    HIPCHK(frechet_alloc(f, kFmData, sizeof(double) * (size_t)(f->nnz ? f->nnz : 1)));
+    hipLaunchKernelGGL(k_csr_emit, dim3((unsigned)f->num), dim3(256), 0, ctx->stream, f->ucols(), f->uvals(),
+                       f->uoff(), f->indptr(), f->droptol, f->indices(), f->data());
+    HIPCHK(hipGetLastError());
+    f->csr_built = true;
     return RAY_OK;
 }
 
@@ -1644,11 +1668,12 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     if (num > 0x7fffffff / 4) return fail(RAY_ERR_INVALID, "too many rays for one call (4 num must fit in int32)");
     if (!(dt > 0)) return fail(RAY_ERR_INVALID, "dt must be > 0");
     ray_frechet *f = new ray_frechet;
-    f->ctx = ctx; f->num = num; f->N = med->N;
+    f->ctx = ctx; f->num = num; f->N = med->N; f->droptol = droptol;
     ctx->frechets.push_back(f);
     if (num == 0) {
-        if (frechet_alloc(f, 0, sizeof(int64_t)) != hipSuccess ||
-            hipMemsetAsync(f->d_indptr, 0, sizeof(int64_t), ctx->stream) != hipSuccess ||
+        if (frechet_alloc(f, kFmIndptr, sizeof(int64_t)) != hipSuccess || frechet_alloc(f, kFmUoff, sizeof(int64_t)) != hipSuccess ||
+            hipMemsetAsync(f->indptr(), 0, sizeof(int64_t), ctx->stream) != hipSuccess ||
+            hipMemsetAsync(f->uoff(), 0, sizeof(int64_t), ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             ray_frechet_destroy(f);
             return fail(RAY_ERR_HIP, "ray_forward_operator: allocation failed");
@@ -1656,8 +1681,8 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         *out = f;
         return RAY_OK;
     }
-    // The stencil slab needs 480 B per ray-step: rays go through in chunks (whole waves) that keep it
-    // within a budget, and the CSR pieces are concatenated (rows are ray-ordered, chunks contiguous).
+    // The trajectory slab and the sort's hand-over need 180 B per ray-step: rays go through in chunks (whole
+    // waves) that keep them within a budget, and the block rows are concatenated (ray-ordered, chunks contiguous).
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { ray_frechet_destroy(f); return fail(RAY_ERR_HIP, "hipMemGetInfo failed"); }
     const char *env_slab = getenv("RAY_FRECHET_SLAB_MB");                 // tests force small chunks with it
@@ -1669,7 +1694,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
         for (int64_t w0 = 0; w0 < num; w0 += 64) {
             double tmax = 0;
             for (int64_t r = w0; r < num && r < w0 + 64; ++r) tmax = std::max(tmax, m_host[r + 8 * ld] > 0 ? m_host[r + 8 * ld] : 0.0);
-            const double bytes = tmax > 0 ? (std::floor(tmax / dt) + 3) * 12 * 64 * 40.0 : 0.0;
+            const double bytes = tmax > 0 ? (std::floor(tmax / dt) + 3) * 64 * (double)kTrajBytesPerRow : 0.0;
             if (acc > 0 && acc + bytes > budget) { cuts.push_back(w0); acc = 0; }
             acc += bytes;
         }
@@ -1687,11 +1712,11 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     }
     std::vector<ray_frechet *> pieces;
     auto drop = [&]() { for (ray_frechet *q : pieces) ray_frechet_destroy(q); ray_frechet_destroy(f); };
-    int64_t nnz = 0;
+    int64_t nnz = 0, U = 0;
     for (size_t c = 0; c + 1 < cuts.size(); ++c) {
         const int64_t r0 = cuts[c], n = cuts[c + 1] - r0;
         ray_frechet *q = new ray_frechet;
-        q->ctx = ctx; q->num = n; q->N = med->N;
+        q->ctx = ctx; q->num = n; q->N = med->N; q->droptol = droptol;
         ctx->frechets.push_back(q);
         pieces.push_back(q);
         rc = forward_operator_impl(ctx, med, m_host + r0, n, ld, dt, droptol, X_host + r0, ldx,
@@ -1699,20 +1724,28 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
                                    nsteps ? nsteps + r0 : nullptr, q);
         if (rc) { (void)hipStreamSynchronize(ctx->stream); drop(); return rc; }
         nnz += q->nnz;
+        U += q->U;
     }
-    hipError_t e = frechet_alloc(f, 0, sizeof(int64_t) * (size_t)(4 * num + 1));
-    if (e == hipSuccess) e = frechet_alloc(f, 1, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
-    if (e == hipSuccess) e = frechet_alloc(f, 2, sizeof(double) * (size_t)(nnz ? nnz : 1));
-    int64_t at = 0;
+    hipError_t e = frechet_alloc(f, kFmIndptr, sizeof(int64_t) * (size_t)(4 * num + 1));
+    if (e == hipSuccess) e = frechet_alloc(f, kFmUoff, sizeof(int64_t) * (size_t)(num + 1));
+    if (e == hipSuccess) e = frechet_alloc(f, kFmRowcnt, sizeof(int32_t) * 4 * (size_t)num);
+    if (e == hipSuccess) e = frechet_alloc(f, kFmUcols, sizeof(int32_t) * (size_t)(U ? U : 1));
+    if (e == hipSuccess) e = frechet_alloc(f, kFmUvals, sizeof(double) * 4 * (size_t)(U ? U : 1));
+    int64_t at = 0, atU = 0;
     for (size_t c = 0; e == hipSuccess && c < pieces.size(); ++c) {
         ray_frechet *q = pieces[c];
-        const int64_t rows = 4 * q->num + (c + 1 == pieces.size() ? 1 : 0);       // the last piece also brings the end marker
+        const int last = c + 1 == pieces.size() ? 1 : 0;                          // the last piece also brings the end markers
+        const int64_t rows = 4 * q->num + last, rays = q->num + last;
         hipLaunchKernelGGL(k_indptr_shift, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream,
-                           f->d_indptr + 4 * cuts[c], q->d_indptr, rows, at);
+                           f->indptr() + 4 * cuts[c], q->indptr(), rows, at);
+        hipLaunchKernelGGL(k_indptr_shift, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, ctx->stream,
+                           f->uoff() + cuts[c], q->uoff(), rays, atU);
         e = hipGetLastError();
-        if (e == hipSuccess && q->nnz) e = hipMemcpyAsync(f->d_indices + at, q->d_indices, sizeof(int32_t) * (size_t)q->nnz, hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess && q->nnz) e = hipMemcpyAsync(f->d_data + at, q->d_data, sizeof(double) * (size_t)q->nnz, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(f->rowcnt() + 4 * cuts[c], q->rowcnt(), sizeof(int32_t) * 4 * (size_t)q->num, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && q->U) e = hipMemcpyAsync(f->ucols() + atU, q->ucols(), sizeof(int32_t) * (size_t)q->U, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && q->U) e = hipMemcpyAsync(f->uvals() + 4 * atU, q->uvals(), sizeof(double) * 4 * (size_t)q->U, hipMemcpyDeviceToDevice, ctx->stream);
         at += q->nnz;
+        atU += q->U;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -1722,6 +1755,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     }
     for (ray_frechet *q : pieces) ray_frechet_destroy(q);
     f->nnz = nnz;
+    f->U = U;
     *out = f;
     return RAY_OK;
 }
@@ -1741,20 +1775,35 @@ int ray_frechet_export_csr(ray_frechet *f, int64_t *indptr, int32_t *indices, do
     if (f->nnz && (!indices || !data)) return fail(RAY_ERR_INVALID, "null indices / data");
     int rc = use(f->ctx);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(indptr, f->d_indptr, sizeof(int64_t) * (size_t)(4 * f->num + 1), hipMemcpyDeviceToHost));
+    if ((rc = ensure_csr(f))) return rc;
+    HIPCHK(hipMemcpyAsync(indptr, f->indptr(), sizeof(int64_t) * (size_t)(4 * f->num + 1), hipMemcpyDeviceToHost, f->ctx->stream));
     if (f->nnz) {
-        HIPCHK(hipMemcpy(indices, f->d_indices, sizeof(int32_t) * (size_t)f->nnz, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(data, f->d_data, sizeof(double) * (size_t)f->nnz, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(indices, f->indices(), sizeof(int32_t) * (size_t)f->nnz, hipMemcpyDeviceToHost, f->ctx->stream));
+        HIPCHK(hipMemcpyAsync(data, f->data(), sizeof(double) * (size_t)f->nnz, hipMemcpyDeviceToHost, f->ctx->stream));
     }
+    HIPCHK(hipStreamSynchronize(f->ctx->stream));
     return RAY_OK;
 }
 
 int ray_frechet_csr_dev(ray_frechet *f, const int64_t **indptr, const int32_t **indices, const double **data)
 {
     if (!f) return fail(RAY_ERR_INVALID, "null handle");
-    if (indptr) *indptr = f->d_indptr;
-    if (indices) *indices = f->d_indices;
-    if (data) *data = f->d_data;
+    int rc = use(f->ctx);
+    if (rc) return rc;
+    if ((indices || data) && (rc = ensure_csr(f))) return rc;           // converted on the context's stream
+    if (indptr) *indptr = f->indptr();
+    if (indices) *indices = f->indices();
+    if (data) *data = f->data();
+    return RAY_OK;
+}
+
+int ray_frechet_block_rows_dev(ray_frechet *f, int64_t *n_entries, const int64_t **uoff, const int32_t **ucols, const double **uvals)
+{
+    if (!f) return fail(RAY_ERR_INVALID, "null handle");
+    if (n_entries) *n_entries = f->U;
+    if (uoff) *uoff = f->uoff();
+    if (ucols) *ucols = f->ucols();
+    if (uvals) *uvals = f->uvals();
     return RAY_OK;
 }
 
@@ -1772,8 +1821,7 @@ int ray_frechet_dofs_dev(ray_frechet *f, const double *fidelity_dev, double *dof
     if (rc) return rc;
     if (!fidelity_dev || !dofs_dev) return fail(RAY_ERR_INVALID, "null argument");
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_dofs, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr, f->d_indices,
-                       fidelity_dev, f->num, dofs_dev);
+    hipLaunchKernelGGL(k_br_dofs, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), fidelity_dev, dofs_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
@@ -1784,8 +1832,7 @@ int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev)
     if (rc) return rc;
     if (!x_dev || !y_dev) return fail(RAY_ERR_INVALID, "null argument");
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_matvec, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
-                       f->d_indices, f->d_data, x_dev, 4 * f->num, y_dev);
+    hipLaunchKernelGGL(k_br_matvec, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), x_dev, y_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
@@ -1797,8 +1844,7 @@ int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t 
     if (!v_dev || !b_dev) return fail(RAY_ERR_INVALID, "null argument");
     HIPCHK(hipMemsetAsync(b_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_matvec_t, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
-                       f->d_indices, f->d_data, v_dev, ray_mask_dev, 4 * f->num, b_dev);
+    hipLaunchKernelGGL(k_br_matvec_t, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), v_dev, ray_mask_dev, b_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
@@ -1810,8 +1856,7 @@ int ray_frechet_normal_matvec_dev(ray_frechet *f, const double *x_dev, const uin
     if (!x_dev || !w_dev || x_dev == w_dev) return fail(RAY_ERR_INVALID, "null argument / x and w must differ");
     HIPCHK(hipMemsetAsync(w_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_normal_matvec, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
-                       f->d_indices, f->d_data, x_dev, ray_mask_dev, 4 * f->num, w_dev);
+    hipLaunchKernelGGL(k_br_normal_matvec, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), x_dev, ray_mask_dev, w_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
@@ -1823,8 +1868,7 @@ int ray_frechet_normal_diag_dev(ray_frechet *f, const uint8_t *ray_mask_dev, dou
     if (!d_dev) return fail(RAY_ERR_INVALID, "null argument");
     HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_normal_diag, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
-                       f->d_indices, f->d_data, ray_mask_dev, 4 * f->num, d_dev);
+    hipLaunchKernelGGL(k_br_normal_diag, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), ray_mask_dev, d_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
@@ -1837,9 +1881,8 @@ int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const d
     if (rc) return rc;
     if (!x_dev || !mismatch_dev || !fidelity_dev) return fail(RAY_ERR_INVALID, "null argument");
     if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_csr_fidelity, dim3(wave_rows_grid(4 * f->num)), dim3(256), 0, f->ctx->stream, f->d_indptr,
-                       f->d_indices, f->d_data, x_dev, mismatch_dev, ray_mask_dev, rejection, decay, 4 * f->num,
-                       fidelity_dev, residual_dev);
+    hipLaunchKernelGGL(k_br_fidelity, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), x_dev, mismatch_dev,
+                       ray_mask_dev, rejection, decay, fidelity_dev, residual_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }

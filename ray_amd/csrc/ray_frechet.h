@@ -3,17 +3,21 @@
 // :141-187 ChunkProcessing!, :212-218 hess table, :242 sparse + droptol).
 //
 // The reference builds, per ray and per RK4 step, three 4 x N^2 sparse matrices (O(N^2) each) and a
-// dense 4num x N^2 SharedArray that it then compresses.  Here the sparse matrix is built on the device:
-//   k_frechet      one thread integrates (X, rho) of one ray and EMITS the 12-node stencil
-//                  contributions Theta = inv(rho) dV w of every trajectory node into its ray's own
-//                  contiguous stretch of the slab (8-byte keys, 32-byte values): the merge kernels
-//                  read a ray's entries as one stream;
-//   k_merge_sort   one workgroup per ray sorts that ray's (node, emission order) keys in LDS and
-//                  ranks the distinct nodes;
-//   k_merge_emit   sums each node's contributions in emission order (the order of the reference's
-//                  Phi += Theta), applies the final rho (M rows = rho * Phi, :184) and counts the
-//                  entries that survive droptol per matrix row;
-//   k_csr_emit     writes the CSR arrays (rows ray-major like reshape(M, 4num, N^2), columns sorted).
+// dense 4num x N^2 SharedArray that it then compresses.  Here the matrix is built on the device:
+//   k_frechet      one thread integrates (X, rho) of one ray and leaves ONE 128-byte record per trajectory
+//                  node in its ray's own contiguous stretch of the trajectory slab -- the three 4-vectors
+//                  P, Q, S that Theta = inv(rho) dV w factors into, the in-cell offsets and the cell -- plus
+//                  the cell alone in a compact [wave][step][lane] array for the sort;
+//   k_merge_sort   one workgroup per ray sorts that ray's (node, emission order) keys -- 12 stencil nodes
+//                  per record, derived from the cell -- in LDS, ranks the distinct nodes and hands over
+//                  4 bytes per entry (rank | head flag | emission index);
+//   k_merge_emit   rebuilds each entry's Theta column from its record (held in LDS), sums every node's
+//                  contributions in emission order (the order of the reference's Phi += Theta), applies the
+//                  final rho (M rows = rho * Phi, :184) and writes the ray's BLOCK ROW: one column index and
+//                  the four values of rows 4 ray .. 4 ray + 3 per distinct node (36 B instead of 48 B of CSR);
+//                  it also counts, per matrix row, the entries that survive droptol.
+// The block rows are the device-resident form of M: the loop passes (k_br_*) apply droptol on the fly.
+//   k_csr_emit     converts to CSR (rows ray-major like reshape(M, 4num, N^2), columns sorted) on export only.
 // The reference goes through LAPACK inv / BLAS gemm here, so parity is by tolerance; the X
 // trajectory itself is bit-identical to k_trace (same expressions).
 #pragma once
@@ -197,10 +201,10 @@ struct FrechetArgs {
     double dt;
     int max_steps;
     double cease_r;
-    const int64_t *wave_base;   // slot-row offset of every wave (a wave owns 64 x rows entries from 64 * base)
-    const int32_t *wave_cap;    // step capacity of every wave (rows = 12 * (cap + 1) entries per ray)
-    int64_t *keys;              // [wave][lane][row] node index (0-based, first index x) or -1
-    double *vals;               // [wave][lane][row][4]
+    const int64_t *wave_base;   // record-row offset of every wave (a wave owns 64 x rows records from 64 * base)
+    const int32_t *wave_cap;    // step capacity of every wave (rows = cap + 1 records per ray)
+    double *traj;               // [wave][lane][row][16] trajectory records (kTrajDoubles)
+    int32_t *cells;             // [wave][row][lane] cell of every trajectory node: i | j << 16
     double *X;                  // (num, 4) end states
     int64_t ldx;
     double *rho;                // (num, 16) final Jacobian, row-major
@@ -208,97 +212,80 @@ struct FrechetArgs {
     unsigned long long *step_counter;
 };
 
-constexpr uint64_t kKeyDead = ~0ull;    // sorted key layout: node << 40 | emission index << 20 | rank
-constexpr int kMergeMaxEntries = 16384; // per ray: 128 KiB of LDS keys
+// Trajectory record: Theta (4 x 12) = inv(rho) dV(X) w is a combination of three 4-vectors with the
+// twelve bilinear weights of the node's cell (NonObstacle.jl:107-139 has only those three column patterns):
+//   P = inv * [2c px, 2c py, -tau gcX, -tau gcY] * w,  Q = inv[:,2] * (c tau / 2h) * w,  S = inv[:,3] * (c tau / 2h) * w
+//   cell nodes k = 0..3:  phi_k P + psi_k Q + gam_k S;  x-neighbours: -psi_k Q;  y-neighbours: -gam_k S
+// [ P | Q | S | u v cell - ]: 128 bytes per node instead of 12 x 40 bytes of (key, Theta column).
+constexpr int kTrajDoubles = 16;
+constexpr int kTrajBytesPerRow = kTrajDoubles * 8 + kFrSlotsPerCall * 4 + 4;   // record + sorted entries + cell
+constexpr uint32_t kSrtDead = 0xffffffffu;  // sorted entry: rank << 15 | head << 14 | emission index
+constexpr int kMergeMaxEntries = 16384;     // per ray (emission index: 14 bits; 64 KiB of 32-bit LDS keys)
+constexpr uint64_t kKeyDead = ~0ull;        // wide sort key: node << 40 | emission index << 20
 
-__host__ __device__ inline int frechet_entries(int steps) { return steps > 0 ? (steps + 1) * kFrSlotsPerCall : 0; }
+__host__ __device__ inline int frechet_rows(int steps) { return steps > 0 ? steps + 1 : 0; }
+__host__ __device__ inline int frechet_entries(int steps) { return frechet_rows(steps) * kFrSlotsPerCall; }
 
-// first slab entry of ray `lane` of a wave whose rays hold frechet_entries(cap) entries each
-__device__ __forceinline__ int64_t ray_slab0(int64_t wave_base, int cap, int lane)
+// first record row of ray `lane` of a wave whose rays hold frechet_rows(cap) records each
+__device__ __forceinline__ int64_t ray_row0(int64_t wave_base, int cap, int lane)
 {
-    return wave_base * 64 + (int64_t)lane * frechet_entries(cap);
+    return wave_base * 64 + (int64_t)lane * frechet_rows(cap);
 }
 
-// Theta = inv(rho) * dV(X) * w for the 12 stencil nodes of X's cell -> entries [12 it, 12 it + 12) of
-// this lane's ray.  dV: NonObstacle.jl:107-139.  (ALL 64 lanes of the one-wave workgroup together.)
-// A ray's entries are contiguous in the slab, so lane-wise stores would touch 64 lines per
-// instruction: the wave transposes four entries per lane at a time through LDS (2 KB of keys, 8 KB
-// of values) and stores them as 16-byte pieces, consecutive lanes on consecutive pieces of one ray
-// (values: 8 lanes = one ray's 128 bytes).  Finished lanes' pieces are not stored: nobody reads them.
-constexpr int kFrStageBytes = 64 * 4 * 8 + 64 * 4 * 32;
+// stencil node k of cell (i, j): cell nodes, x-neighbours (row 3 of dV), y-neighbours (row 4)
+//   di = {0, 1, 0, 1, 2, -1, 2, -1, 0, 1, 0, 1},  dj = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, -1, -1}
+// packed two bits each as offset + 1 (register constants: no table look-up by a runtime k)
+__device__ __forceinline__ int stencil_di(int k) { return (int)((0x993399u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ int stencil_dj(int k) { return (int)((0x0fa5a5u >> (2 * k)) & 3u) - 1; }
+
+// One trajectory record per live lane -> row `it` of the lane's ray (ALL 64 lanes of the one-wave workgroup
+// together).  A ray's records are contiguous in the slab, so lane-wise stores would touch 64 lines per
+// instruction: the wave transposes through LDS (64 x 144 B, rows padded by 16 B against bank conflicts) and
+// stores 16-byte pieces, 8 consecutive lanes on the 8 pieces of one ray's 128-byte record = one full line.
+// Finished lanes' records are not stored: nobody reads them.
+constexpr int kFrStageBytes = 64 * 144;
 __host__ __device__ inline size_t frechet_lds_bytes(int N) { return (((size_t)N * 8 + 15) & ~(size_t)15) + kFrStageBytes; }
 
 template <int AR>
-__device__ __forceinline__ void emit_theta(const FrechetArgs &a, const double X[4], const PointEval &q, int o,
-                                           const double rho[16], double w,
-                                           bool live, int64_t wave_slab0, int rows, int it, unsigned lane, int &oob)
+__device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4], const PointEval &q, int o,
+                                          const double rho[16], double w,
+                                          bool live, int64_t wave_base, int64_t wave_row0, int rows, int it, unsigned lane, int &oob)
 {
     double inv[16];
     mat4_inv(rho, inv);
     const GridDev &g = a.med.g;
     const double h = g.h;
     const double u = q.dx / h, v = q.dy / h;
-    const double phi[4] = {(1 - u) * (1 - v), u * (1 - v), (1 - u) * v, u * v};
-    const double psi[4] = {u * (1 - v), -(1 - u) * (1 - v), u * v, -(1 - u) * v};
-    const double gam[4] = {(1 - u) * v, u * v, -(1 - u) * (1 - v), -u * (1 - v)};
-    const double ct2h = q.c * q.tau / (2 * h);
+    const double ctw = (q.c * q.tau / (2 * h)) * w;
+    const double a0 = (2 * q.c * X[2]) * w, a1 = (2 * q.c * X[3]) * w, a2 = (-q.tau * q.gcX) * w, a3 = (-q.tau * q.gcY) * w;
     const int N = g.N;
-    // node offsets relative to (i, j): cell nodes, x-neighbours (row 3), y-neighbours (row 4)
-    const int di[12] = {0, 1, 0, 1, 2, -1, 2, -1, 0, 1, 0, 1};
-    const int dj[12] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, -1, -1};
-    char *stage = ray_smem + (((size_t)N * 8 + 15) & ~(size_t)15);
-    int64_t *skeys = reinterpret_cast<int64_t *>(stage);                    // [lane][4]
-    double2 *svals = reinterpret_cast<double2 *>(stage + 64 * 4 * 8);       // [lane][4][2]
-    const unsigned long long lm = __ballot(live);
+    // the stencil reaches i-1 .. i+2, j-1 .. j+2: nodes off the grid are dropped and flagged
+    o |= (q.i < 1) | (q.i + 2 >= N) | (q.j < 1) | (q.j + 2 >= N);
+    double2 *stage = reinterpret_cast<double2 *>(ray_smem + (((size_t)N * 8 + 15) & ~(size_t)15));   // [lane][9]
+    double2 *mine = stage + lane * 9;
 #pragma unroll
-    for (int grp = 0; grp < 3; ++grp) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int k = grp * 4 + kk;
-            const int ni = q.i + di[k], nj = q.j + dj[k];
-            const bool ok = ni >= 0 && ni < N && nj >= 0 && nj < N;
-            o |= !ok;
-            double th[4];
-            if (k < 4) {
-                const double A0 = 2 * q.c * X[2] * phi[k], A1 = 2 * q.c * X[3] * phi[k];
-                const double A2 = -q.tau * q.gcX * phi[k] + ct2h * psi[k];
-                const double A3 = -q.tau * q.gcY * phi[k] + ct2h * gam[k];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    th[r] = (((inv[r * 4] * A0 + inv[r * 4 + 1] * A1) + inv[r * 4 + 2] * A2) + inv[r * 4 + 3] * A3) * w;
-            } else if (k < 8) {
-                const double A2 = -ct2h * psi[k - 4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 2] * A2) * w;
-            } else {
-                const double A3 = -ct2h * gam[k - 8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) th[r] = (inv[r * 4 + 3] * A3) * w;
-            }
-            skeys[lane * 4 + kk] = ok ? (int64_t)(ni + nj * N) : (int64_t)-1;
-            svals[(lane * 4 + kk) * 2] = make_double2(th[0], th[1]);
-            svals[(lane * 4 + kk) * 2 + 1] = make_double2(th[2], th[3]);
-        }
-        __syncthreads();
-        const int64_t e0 = (int64_t)it * kFrSlotsPerCall + grp * 4;          // first entry of this group in a ray
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {                                         // keys: 128 pieces, 2 per ray
-            const unsigned qq = t * 64 + lane, ray = qq >> 1, part = qq & 1;
-            if ((lm >> ray) & 1) {
-                const double2 piece = reinterpret_cast<const double2 *>(skeys)[qq];
-                *reinterpret_cast<double2 *>(a.keys + wave_slab0 + (int64_t)ray * rows + e0 + part * 2) = piece;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {                                         // values: 512 pieces, 8 per ray
-            const unsigned qq = t * 64 + lane, ray = qq >> 3, part = qq & 7;
-            if ((lm >> ray) & 1) {
-                const double2 piece = svals[qq];
-                *reinterpret_cast<double2 *>(a.vals + (wave_slab0 + (int64_t)ray * rows + e0) * 4 + part * 2) = piece;
-            }
-        }
-        __syncthreads();
+    for (int r = 0; r < 4; r += 2) {
+        const double p0 = ((inv[r * 4] * a0 + inv[r * 4 + 1] * a1) + inv[r * 4 + 2] * a2) + inv[r * 4 + 3] * a3;
+        const double p1 = ((inv[r * 4 + 4] * a0 + inv[r * 4 + 5] * a1) + inv[r * 4 + 6] * a2) + inv[r * 4 + 7] * a3;
+        mine[r / 2] = make_double2(p0, p1);
+        mine[2 + r / 2] = make_double2(inv[r * 4 + 2] * ctw, inv[r * 4 + 6] * ctw);
+        mine[4 + r / 2] = make_double2(inv[r * 4 + 3] * ctw, inv[r * 4 + 7] * ctw);
     }
+    const int cellv = q.i | (q.j << 16);
+    mine[6] = make_double2(u, v);
+    mine[7] = make_double2(__longlong_as_double((long long)cellv), 0.0);
+    a.cells[(wave_base + it) * 64 + lane] = live ? cellv : -1;
+    const unsigned long long lm = __ballot(live);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {                                         // 512 pieces, 8 per ray
+        const unsigned qq = t * 64 + lane, ray = qq >> 3, part = qq & 7;
+        if ((lm >> ray) & 1) {
+            const double2 piece = stage[ray * 9 + part];
+            *reinterpret_cast<double2 *>(a.traj + (wave_row0 + (int64_t)ray * rows + it) * kTrajDoubles + part * 2) = piece;
+        }
+    }
+    __syncthreads();
     if (live) oob |= o;
 }
 
@@ -319,8 +306,8 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         __syncthreads();
     }
     const int cap = a.wave_cap[wave];
-    const int64_t wave_slab0 = ray_slab0(a.wave_base[wave], cap, 0);
-    const int rows = frechet_entries(cap);
+    const int64_t wave_base = a.wave_base[wave], wave_row0 = ray_row0(wave_base, cap, 0);
+    const int rows = frechet_rows(cap);
     double X[4] = {0, 0, 1, 0}, T = 0;
     double rho[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int steps = 0, st = 0, oob = 0, it = 0;
@@ -347,7 +334,7 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         PointEval q0;
         int o0 = 0;
         point_eval<AR>(a.med.g, X, k1, q0, o0);
-        emit_theta<AR>(a, X, q0, o0, rho, wp + dtl * 0.5, active || fin, wave_slab0, rows, it, lane, oob);
+        emit_node<AR>(a, X, q0, o0, rho, wp + dtl * 0.5, active || fin, wave_base, wave_row0, rows, it, lane, oob);
         fin = false;
         if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
@@ -406,17 +393,16 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
 
 // ---- merge: distinct nodes of one ray --------------------------------------------------------------
 // One workgroup per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power of
-// two); every entry gets the rank of its node among the ray's distinct nodes and is written back in
-// place as node << 40 | emission << 20 | rank; ucount[ray] = number of distinct nodes.
-// The sort is LDS-bandwidth bound, so the compare-exchange passes with stride < 16 -- the last four of
-// every stage, and all of the first four stages -- run in registers on 16-key chunks: one LDS round
-// trip instead of four.  Keys sit padded by one per 16 (a thread's chunk is 136 bytes from its
-// neighbour's: conflict-free 8-byte reads).
-// chunk = keys a thread sorts in registers = padding period: 16 eight-byte keys, 32 four-byte keys
+// two); every entry gets the rank of its node among the ray's distinct nodes and goes back to memory as
+// rank << 15 | head << 14 | emission index; ucount[ray] = number of distinct nodes.
+// The network runs in ROUNDS: a thread takes eight keys whose indices differ in three bits b..b+2, does
+// the compare-exchanges of up to three consecutive strides (2^(b+2), 2^(b+1), 2^b) in registers and puts
+// them back -- one LDS round trip per three strides, every thread of the workgroup busy in every round
+// (n2 / 8 threads' worth of work: all 256 at the usual n2 = 2048).  Keys sit padded by one per 8: the
+// eight-key groups of consecutive threads then fall on distinct banks for every b.
 __host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes)
 {
-    const int chunk = key_bytes == 4 ? 32 : 16;
-    return (size_t)(n2 + n2 / chunk) * key_bytes;
+    return (size_t)(n2 + n2 / 8) * key_bytes;
 }
 
 // Sort keys.  64-bit: node << 40 | emission << 20.  32-bit (chosen by the host when the node index and
@@ -424,101 +410,112 @@ __host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes)
 // half the LDS traffic, one-instruction compares, min/max exchanges.
 template <typename K> struct SortKey;
 template <> struct SortKey<uint64_t> {
-    static constexpr int kChunk = 16, kShift = 4;
     static __device__ __forceinline__ uint64_t dead() { return kKeyDead; }
     static __device__ __forceinline__ uint64_t pack(int64_t node, int e, int) { return (uint64_t)node << 40 | (uint64_t)e << 20; }
     static __device__ __forceinline__ uint64_t node(uint64_t k, int) { return k >> 40; }
-    static __device__ __forceinline__ uint64_t out(uint64_t k, int, int rank) { return k | (uint64_t)rank; }
+    static __device__ __forceinline__ uint32_t emission(uint64_t k, int) { return (uint32_t)(k >> 20) & 0xFFFFFu; }
 };
 template <> struct SortKey<uint32_t> {
-    static constexpr int kChunk = 32, kShift = 5;
     static __device__ __forceinline__ uint32_t dead() { return 0xffffffffu; }
     static __device__ __forceinline__ uint32_t pack(int64_t node, int e, int es) { return (uint32_t)node << es | (uint32_t)e; }
     static __device__ __forceinline__ uint64_t node(uint32_t k, int es) { return k >> es; }
-    static __device__ __forceinline__ uint64_t out(uint32_t k, int es, int rank)
-    {
-        return (uint64_t)(k >> es) << 40 | (uint64_t)(k & ((1u << es) - 1u)) << 20 | (uint64_t)rank;
-    }
+    static __device__ __forceinline__ uint32_t emission(uint32_t k, int es) { return k & ((1u << es) - 1u); }
 };
 
-// strides min(size/2, chunk/2) .. 1 of bitonic stage `size` on the chunk that starts at key c0
 template <typename K>
-__device__ __forceinline__ void sort_chunk_stage(K v[SortKey<K>::kChunk], int c0, int size)
+__device__ __forceinline__ void cmp_exchange(K &x, K &y, bool up)
 {
-    constexpr int kSortChunk = SortKey<K>::kChunk;
+    const K mn = x < y ? x : y, mx = x < y ? y : x;
+    x = up ? mn : mx;
+    y = up ? mx : mn;
+}
+
+// the compare-exchanges of the strides 2^(nstr-1) .. 1 (in units of the group's own spacing) on eight keys
+template <typename K>
+__device__ __forceinline__ void sort_group_strides(K v[8], int nstr, bool up)
+{
 #pragma unroll
-    for (int stride = kSortChunk / 2; stride > 0; stride >>= 1) {
-        if (stride < size) {
+    for (int sb = 2; sb >= 0; --sb) {
+        if (sb < nstr) {
 #pragma unroll
-            for (int p = 0; p < kSortChunk / 2; ++p) {
-                const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1)), hi = lo + stride;
-                const bool up = ((c0 + lo) & size) == 0;
-                const K x = v[lo], y = v[hi];
-                const K mn = x < y ? x : y, mx = x < y ? y : x;
-                v[lo] = up ? mn : mx;
-                v[hi] = up ? mx : mn;
+            for (int p = 0; p < 4; ++p) {
+                const int lo = ((p >> sb) << (sb + 1)) | (p & ((1 << sb) - 1));
+                cmp_exchange<K>(v[lo], v[lo | (1 << sb)], up);
             }
         }
     }
 }
 
 template <int BT, typename K>
-__global__ __launch_bounds__(BT) void k_merge_sort(int64_t *__restrict__ keys, const int64_t *__restrict__ wave_base,
+__global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ cells, uint32_t *__restrict__ srt,
+                                                    const int64_t *__restrict__ wave_base,
                                                     const int32_t *__restrict__ wave_cap,
-                                                    const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift)
+                                                    const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift, int N)
 {
     typedef SortKey<K> SK;
-    constexpr int kSortChunk = SK::kChunk;
-    auto spad = [](int i) { return i + (i >> SK::kShift); };
+    auto spad = [](int i) { return i + (i >> 3); };
     K *sk = reinterpret_cast<K *>(ray_smem);
     __shared__ int s_cnt[BT];
+    __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 1];
     const int64_t ray = blockIdx.x;
     const int tid = threadIdx.x;
-    const int ne = frechet_entries(nsteps[ray]);
+    const int nrow = frechet_rows(nsteps[ray]);
+    const int ne = nrow * kFrSlotsPerCall;
     if (ne == 0) {
         if (tid == 0) ucount[ray] = 0;
         return;
     }
     int n2 = 256;
     while (n2 < ne) n2 <<= 1;
-    int64_t *rk = keys + ray_slab0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
+    const int64_t wb = wave_base[ray >> 6];
+    const int lane = (int)(ray & 63);
+    uint32_t *rk = srt + ray_row0(wb, wave_cap[ray >> 6], lane) * kFrSlotsPerCall;
+    for (int r = tid; r < nrow; r += BT) s_cell[r] = cells[(wb + r) * 64 + lane];
+    __syncthreads();
     for (int e = tid; e < n2; e += BT) {
-        int64_t k = -1;
-        if (e < ne) k = rk[e];
-        sk[spad(e)] = k < 0 ? SK::dead() : SK::pack(k, e, eshift);
+        K key = SK::dead();
+        if (e < ne) {
+            const int r = (int)(((unsigned)e * 43691u) >> 19), k = e - r * kFrSlotsPerCall;     // e / 12 for e < 2^16
+            const int cv = s_cell[r];
+            const int ni = (cv & 0xffff) + stencil_di(k), nj = (cv >> 16) + stencil_dj(k);
+            if (ni >= 0 && ni < N && nj >= 0 && nj < N) key = SK::pack((int64_t)ni + (int64_t)nj * N, e, eshift);
+        }
+        sk[spad(e)] = key;
     }
     __syncthreads();
-    const int nchunk = n2 / kSortChunk;
-    for (int c = tid; c < nchunk; c += BT) {                       // stages 2, 4, 8, 16 entirely in registers
-        K v[kSortChunk];
+    const int ngroup = n2 >> 3;
+    for (int t = tid; t < ngroup; t += BT) {                       // stages 2, 4, 8 on eight consecutive keys
+        K v[8];
 #pragma unroll
-        for (int j = 0; j < kSortChunk; ++j) v[j] = sk[c * (kSortChunk + 1) + j];
+        for (int j = 0; j < 8; ++j) v[j] = sk[t * 9 + j];
 #pragma unroll
-        for (int size = 2; size <= kSortChunk; size <<= 1) sort_chunk_stage<K>(v, c * kSortChunk, size);
+        for (int size = 2; size <= 8; size <<= 1)
 #pragma unroll
-        for (int j = 0; j < kSortChunk; ++j) sk[c * (kSortChunk + 1) + j] = v[j];
+            for (int stride = size >> 1; stride > 0; stride >>= 1)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
+                    cmp_exchange<K>(v[lo], v[lo + stride], ((t * 8 + lo) & size) == 0);
+                }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sk[t * 9 + j] = v[j];
     }
     __syncthreads();
-    for (int size = 2 * kSortChunk; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride >= kSortChunk; stride >>= 1) {
-            const int sm = stride - 1;                                   // strides are powers of two
-            for (int t = tid; t < (n2 >> 1); t += BT) {
-                const int lo = ((t & ~sm) << 1) | (t & sm), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const K x = sk[spad(lo)], y = sk[spad(hi)];
-                if ((x > y) == up) { sk[spad(lo)] = y; sk[spad(hi)] = x; }
+    for (int size = 16, top0 = 3; size <= n2; size <<= 1, ++top0) {
+        for (int top = top0; top >= 0;) {                          // strides 2^top .. 2^b of this stage in one round
+            const int b = top >= 2 ? top - 2 : 0;
+            for (int t = tid; t < ngroup; t += BT) {
+                const int base = ((t >> b) << (b + 3)) | (t & ((1 << b) - 1));
+                K v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = sk[spad(base | (j << b))];
+                sort_group_strides<K>(v, top - b + 1, (base & size) == 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sk[spad(base | (j << b))] = v[j];
             }
             __syncthreads();
+            top = b - 1;
         }
-        for (int c = tid; c < nchunk; c += BT) {
-            K v[kSortChunk];
-#pragma unroll
-            for (int j = 0; j < kSortChunk; ++j) v[j] = sk[c * (kSortChunk + 1) + j];
-            sort_chunk_stage<K>(v, c * kSortChunk, size);
-#pragma unroll
-            for (int j = 0; j < kSortChunk; ++j) sk[c * (kSortChunk + 1) + j] = v[j];
-        }
-        __syncthreads();
     }
     // rank of each entry's node: heads counted per contiguous chunk, scanned over the BT threads
     const int cs = n2 / BT, e0 = tid * cs;
@@ -539,63 +536,119 @@ __global__ __launch_bounds__(BT) void k_merge_sort(int64_t *__restrict__ keys, c
     if (tid == BT - 1) ucount[ray] = s_cnt[BT - 1];
     for (int e = e0; e < e0 + cs; ++e) {
         const K k = sk[spad(e)];
-        if (k == SK::dead()) { if (e < ne) rk[e] = -1; continue; }
-        rank += (e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift));
-        rk[e] = (int64_t)SK::out(k, eshift, rank);
+        if (k == SK::dead()) { if (e < ne) rk[e] = kSrtDead; continue; }
+        const bool head = e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift);
+        rank += head;
+        rk[e] = (uint32_t)rank << 15 | (uint32_t)head << 14 | SK::emission(k, eshift);
+    }
+}
+
+// Theta column of emission e = 12 row + k from the ray's trajectory records (see kTrajDoubles)
+__device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, unsigned e, int N, double th[4], int &node)
+{
+    const unsigned r = (e * 43691u) >> 19, k = e - r * (unsigned)kFrSlotsPerCall;
+    const double2 *rec = reinterpret_cast<const double2 *>(recs + (size_t)r * kTrajDoubles);
+    const double2 uv = rec[6];
+    const int cv = (int)__double_as_longlong(rec[7].x);
+    node = ((cv & 0xffff) + stencil_di((int)k)) + ((cv >> 16) + stencil_dj((int)k)) * N;
+    const double u = uv.x, v = uv.y, a = 1 - u, b = 1 - v;
+    const unsigned kk = k & 3u;
+    // t = {ab, ub, av, uv}: phi_kk = t[kk], psi_kk = +-t[kk ^ 1] (minus for odd kk), gam_kk = +-t[kk ^ 2] (minus for kk >= 2)
+    const double fx0 = (kk & 1u) ? u : a, fx1 = (kk & 1u) ? a : u;         // x factor of t[kk], of t[kk ^ 1]
+    const double fy0 = (kk & 2u) ? v : b, fy1 = (kk & 2u) ? b : v;         // y factor of t[kk], of t[kk ^ 2]
+    const double phi = fx0 * fy0;
+    const double psi = (kk & 1u) ? -(fx1 * fy0) : fx1 * fy0;
+    const double gam = (kk & 2u) ? -(fx0 * fy1) : fx0 * fy1;
+    if (k < 4u) {
+        const double2 p0 = rec[0], p1 = rec[1], q0 = rec[2], q1 = rec[3], s0 = rec[4], s1 = rec[5];
+        th[0] = (phi * p0.x + psi * q0.x) + gam * s0.x;
+        th[1] = (phi * p0.y + psi * q0.y) + gam * s0.y;
+        th[2] = (phi * p1.x + psi * q1.x) + gam * s1.x;
+        th[3] = (phi * p1.y + psi * q1.y) + gam * s1.y;
+    } else {
+        const bool xs = k < 8u;
+        const double2 c0 = xs ? rec[2] : rec[4], c1 = xs ? rec[3] : rec[5];
+        const double f = xs ? -psi : -gam;
+        th[0] = f * c0.x; th[1] = f * c0.y; th[2] = f * c1.x; th[3] = f * c1.y;
     }
 }
 
 // sums every distinct node's contributions in emission order, applies rho, writes the ray's block row
 // (ucols, uvals[4]) at uoff[ray] and the per-matrix-row entry counts that survive droptol.
-__global__ __launch_bounds__(256) void k_merge_emit(const int64_t *__restrict__ keys, const double *__restrict__ vals,
+// The ray's records sit in LDS when they fit `lds_rows` (dynamic shared memory), else they are read in place.
+__global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__ srt, const double *__restrict__ traj,
                                                     const int64_t *__restrict__ wave_base, const int32_t *__restrict__ wave_cap,
                                                     const int32_t *__restrict__ nsteps,
                                                     const double *__restrict__ rho, const int64_t *__restrict__ uoff,
-                                                    double droptol, int32_t *__restrict__ ucols,
+                                                    double droptol, int N, int lds_rows, int32_t *__restrict__ ucols,
                                                     double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
 {
     __shared__ int s_rows[4];
     const int64_t ray = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid < 4) s_rows[tid] = 0;
+    const int nrow = frechet_rows(nsteps[ray]);
+    const int ne = nrow * kFrSlotsPerCall;
+    const int64_t row0 = ray_row0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
+    const uint32_t *rk = srt + row0 * kFrSlotsPerCall;
+    const double *recs = traj + row0 * kTrajDoubles;
+    if (nrow <= lds_rows) {
+        double2 *l2 = reinterpret_cast<double2 *>(ray_smem);
+        const double2 *g2 = reinterpret_cast<const double2 *>(recs);
+        for (int k = tid; k < nrow * (kTrajDoubles / 2); k += 256) l2[k] = g2[k];
+        recs = reinterpret_cast<const double *>(ray_smem);
+    }
     __syncthreads();
-    const int ne = frechet_entries(nsteps[ray]);
-    const int64_t slab0 = ray_slab0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
-    const int64_t *rk = keys + slab0;
-    const double *rv = vals + slab0 * 4;
     const int64_t off = uoff[ray];
     double R[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) R[k] = rho[ray * 16 + k];
     int cnt[4] = {0, 0, 0, 0};
-    for (int e = tid; e < ne; e += 256) {
-        const uint64_t k = (uint64_t)rk[e];
-        if (k == kKeyDead) continue;
-        const uint64_t node = k >> 40;
-        if (e > 0 && ((uint64_t)rk[e - 1] >> 40) == node) continue;                          // not a head
+    // Tiles of 256 sorted entries: every thread rebuilds ONE entry's Theta column (no divergence: heads and
+    // followers cost the same), the tile's columns and sorted words go to LDS, then each head adds up its run
+    // from there (a run that leaves the tile is finished from the records directly).
+    __shared__ double2 s_th[256 * 2];
+    __shared__ uint32_t s_w[256];
+    for (int t0 = 0; t0 < ne; t0 += 256) {
+        const int e = t0 + tid;
+        const uint32_t w = e < ne ? rk[e] : kSrtDead;
         double s[4] = {0, 0, 0, 0};
-        uint64_t k2 = k;
-        int e2 = e;
-        bool first = true;
-        do {
-            const double2 *p2 = reinterpret_cast<const double2 *>(rv + (size_t)((k2 >> 20) & 0xFFFFF) * 4);
-            const double2 lo = p2[0], hi = p2[1];
-            if (first) { s[0] = lo.x; s[1] = lo.y; s[2] = hi.x; s[3] = hi.y; first = false; }
-            else { s[0] += lo.x; s[1] += lo.y; s[2] += hi.x; s[3] += hi.y; }                 // Phi += Theta (:159,175)
-            ++e2;
-            k2 = e2 < ne ? (uint64_t)rk[e2] : kKeyDead;
-        } while (k2 != kKeyDead && (k2 >> 40) == node);
-        const int64_t u = off + (int64_t)(k & 0xFFFFF);
-        double o4[4];
+        int node = 0;
+        if (w != kSrtDead) theta_of_entry(recs, w & 0x3FFFu, N, s, node);
+        s_w[tid] = w;
+        s_th[tid * 2] = make_double2(s[0], s[1]);
+        s_th[tid * 2 + 1] = make_double2(s[2], s[3]);
+        __syncthreads();
+        if (w != kSrtDead && (w & 0x4000u)) {                                                // a head
+            for (int e2 = e + 1; e2 < ne; ++e2) {
+                const int q = e2 - t0;
+                double th[4];
+                if (q < 256) {
+                    const uint32_t w2 = s_w[q];
+                    if (w2 == kSrtDead || (w2 & 0x4000u)) break;
+                    const double2 lo = s_th[q * 2], hi = s_th[q * 2 + 1];
+                    th[0] = lo.x; th[1] = lo.y; th[2] = hi.x; th[3] = hi.y;
+                } else {
+                    const uint32_t w2 = rk[e2];
+                    if (w2 == kSrtDead || (w2 & 0x4000u)) break;
+                    int n2_;
+                    theta_of_entry(recs, w2 & 0x3FFFu, N, th, n2_);
+                }
+                s[0] += th[0]; s[1] += th[1]; s[2] += th[2]; s[3] += th[3];                  // Phi += Theta (:159,175)
+            }
+            const int64_t u = off + (int64_t)(w >> 15);
+            double o4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                                                       // rho * Phi (:184)
-            o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
-            cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);                   // droptol! (:242)
+            for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
+                o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
+                cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);               // droptol! (:242)
+            }
+            ucols[u] = (int32_t)node;
+            double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
+            dst[0] = make_double2(o4[0], o4[1]);
+            dst[1] = make_double2(o4[2], o4[3]);
         }
-        ucols[u] = (int32_t)node;
-        double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
-        dst[0] = make_double2(o4[0], o4[1]);
-        dst[1] = make_double2(o4[2], o4[3]);
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -710,75 +763,118 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-// dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])        NonObstacle.jl:340-342; one wave per ray
-__global__ __launch_bounds__(256) void k_csr_dofs(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                  const double *__restrict__ fidelity, int64_t num, double *__restrict__ dofs)
+// The passes below read the BLOCK ROWS: per ray `ray` the distinct nodes uoff[ray] .. uoff[ray+1], each with
+// its column and the values of matrix rows 4 ray .. 4 ray + 3.  An entry belongs to the matrix when it
+// survives droptol (NonObstacle.jl:242), decided on the fly: kept(v).  One wave per ray.
+struct BlockRows {
+    const int64_t *uoff;
+    const int32_t *ucols;
+    const double *uvals;
+    int64_t num;
+    double droptol;
+    __device__ __forceinline__ bool kept(double v) const { return droptol < 0 || __builtin_fabs(v) > droptol; }
+    __device__ __forceinline__ void load(int64_t u, double v[4]) const
+    {
+        const double2 *p2 = reinterpret_cast<const double2 *>(uvals + u * 4);
+        const double2 lo = p2[0], hi = p2[1];
+        v[0] = kept(lo.x) ? lo.x : 0.0; v[1] = kept(lo.y) ? lo.y : 0.0;
+        v[2] = kept(hi.x) ? hi.x : 0.0; v[3] = kept(hi.y) ? hi.y : 0.0;
+    }
+};
+
+// dofs[j] = nnz(M[4j-3,:]) - sum(fidelity[find(M[4j-3,:])])        NonObstacle.jl:340-342
+__global__ __launch_bounds__(256) void k_br_dofs(const BlockRows m, const double *__restrict__ fidelity, double *__restrict__ dofs)
 {
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= num) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t b = indptr[ray * 4], e = indptr[ray * 4 + 1];
-    double s = 0;
-    for (int64_t k = b + lane; k < e; k += 64) s += fidelity[indices[k]];
-    s = wave_sum_f64(s);
-    if (lane == 0) dofs[ray] = (double)(e - b) - s;
-}
-
-// y = M x; one wave per row
-__global__ __launch_bounds__(256) void k_csr_matvec(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                    const double *__restrict__ data, const double *__restrict__ x,
-                                                    int64_t nrows, double *__restrict__ y)
-{
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
+    if (ray >= m.num) return;
     const int lane = threadIdx.x & 63;
     double s = 0;
-    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
+    for (int64_t u = m.uoff[ray] + lane; u < m.uoff[ray + 1]; u += 64)
+        if (m.kept(m.uvals[u * 4])) s += 1.0 - fidelity[m.ucols[u]];
     s = wave_sum_f64(s);
-    if (lane == 0) y[row] = s;
+    if (lane == 0) dofs[ray] = s;
 }
 
-// b += M' (mask .* v): the rows of the selected rays scattered into b (NonObstacle.jl:354); fp64 atomics
-__global__ __launch_bounds__(256) void k_csr_matvec_t(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                      const double *__restrict__ data, const double *__restrict__ v,
-                                                      const uint8_t *__restrict__ ray_mask, int64_t nrows, double *__restrict__ b)
+// the four dot products M[4 ray + r, :] x of one ray (all lanes hold them)
+__device__ __forceinline__ void br_dots(const BlockRows &m, int64_t b, int64_t e, int lane, const double *__restrict__ x, double s[4])
 {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    if (ray_mask && !ray_mask[row >> 2]) return;
+    s[0] = s[1] = s[2] = s[3] = 0.0;
+    for (int64_t u = b + lane; u < e; u += 64) {
+        double v[4];
+        m.load(u, v);
+        const double xv = x[m.ucols[u]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_fma(v[r], xv, s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = wave_sum_f64(s[r]);
+}
+
+// y = M x
+__global__ __launch_bounds__(256) void k_br_matvec(const BlockRows m, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= m.num) return;
     const int lane = threadIdx.x & 63;
-    const double vr = v[row];
-    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) unsafeAtomicAdd(&b[indices[k]], data[k] * vr);
+    double s[4];
+    br_dots(m, m.uoff[ray], m.uoff[ray + 1], lane, x, s);
+    if (lane == 0) {
+        double2 *dst = reinterpret_cast<double2 *>(y + ray * 4);
+        dst[0] = make_double2(s[0], s[1]);
+        dst[1] = make_double2(s[2], s[3]);
+    }
+}
+
+// b += M' (mask .* v): the rows of the selected rays scattered into b (NonObstacle.jl:354); one fp64 atomic
+// per distinct node (the four rows' contributions are added up first)
+__global__ __launch_bounds__(256) void k_br_matvec_t(const BlockRows m, const double *__restrict__ vec,
+                                                     const uint8_t *__restrict__ ray_mask, double *__restrict__ b)
+{
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= m.num) return;
+    if (ray_mask && !ray_mask[ray]) return;
+    const int lane = threadIdx.x & 63;
+    const double2 *v2 = reinterpret_cast<const double2 *>(vec + ray * 4);
+    const double2 lo = v2[0], hi = v2[1];
+    for (int64_t u = m.uoff[ray] + lane; u < m.uoff[ray + 1]; u += 64) {
+        double v[4];
+        m.load(u, v);
+        unsafeAtomicAdd(&b[m.ucols[u]], ((v[0] * lo.x + v[1] * lo.y) + v[2] * hi.x) + v[3] * hi.y);
+    }
 }
 
 // The normal operator of the selected rays without forming it (the reference forms MtM = M[order,Idx]' * M[order,Idx],
 // NonObstacle.jl:353; at N = 1024 that product is out of reach, a Krylov solve needs only its action):
-//   w += M[order,:]' (M[order,:] x), one wave per row: dot with x, then scatter row * dot (the row comes back from L2)
-__global__ __launch_bounds__(256) void k_csr_normal_matvec(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                           const double *__restrict__ data, const double *__restrict__ x,
-                                                           const uint8_t *__restrict__ ray_mask, int64_t nrows, double *__restrict__ w)
+//   w += M[order,:]' (M[order,:] x): the ray's four dots with x, then one atomic per node (the block row comes back from L2)
+__global__ __launch_bounds__(256) void k_br_normal_matvec(const BlockRows m, const double *__restrict__ x,
+                                                          const uint8_t *__restrict__ ray_mask, double *__restrict__ w)
 {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    if (ray_mask && !ray_mask[row >> 2]) return;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= m.num) return;
+    if (ray_mask && !ray_mask[ray]) return;
     const int lane = threadIdx.x & 63;
-    const int64_t b = indptr[row], e = indptr[row + 1];
-    double s = 0;
-    for (int64_t k = b + lane; k < e; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
-    s = wave_sum_f64(s);
-    for (int64_t k = b + lane; k < e; k += 64) unsafeAtomicAdd(&w[indices[k]], data[k] * s);
+    const int64_t b = m.uoff[ray], e = m.uoff[ray + 1];
+    double s[4];
+    br_dots(m, b, e, lane, x, s);
+    for (int64_t u = b + lane; u < e; u += 64) {
+        double v[4];
+        m.load(u, v);
+        unsafeAtomicAdd(&w[m.ucols[u]], ((v[0] * s[0] + v[1] * s[1]) + v[2] * s[2]) + v[3] * s[3]);
+    }
 }
 
 //   d[j] += sum over the selected rows of M[k,j]^2 = diag(MtM): the Jacobi preconditioner of that solve
-__global__ __launch_bounds__(256) void k_csr_normal_diag(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                         const double *__restrict__ data, const uint8_t *__restrict__ ray_mask,
-                                                         int64_t nrows, double *__restrict__ d)
+__global__ __launch_bounds__(256) void k_br_normal_diag(const BlockRows m, const uint8_t *__restrict__ ray_mask, double *__restrict__ d)
 {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
-    if (ray_mask && !ray_mask[row >> 2]) return;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= m.num) return;
+    if (ray_mask && !ray_mask[ray]) return;
     const int lane = threadIdx.x & 63;
-    for (int64_t k = indptr[row] + lane; k < indptr[row + 1]; k += 64) unsafeAtomicAdd(&d[indices[k]], data[k] * data[k]);
+    for (int64_t u = m.uoff[ray] + lane; u < m.uoff[ray + 1]; u += 64) {
+        double v[4];
+        m.load(u, v);
+        unsafeAtomicAdd(&d[m.ucols[u]], ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    }
 }
 
 __device__ __forceinline__ void atomic_max_f64(double *addr, double v)
@@ -794,28 +890,41 @@ __device__ __forceinline__ void atomic_max_f64(double *addr, double v)
 
 // residual[k] = |M[k,:] x - mismatch[k]| for the rows of the selected rays; where residual < rejection,
 // fidelity[find(M[k,:])] = max(fidelity, 1 - decay * residual)     NonObstacle.jl:359-367
-__global__ __launch_bounds__(256) void k_csr_fidelity(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                                      const double *__restrict__ data, const double *__restrict__ x,
-                                                      const double *__restrict__ mismatch, const uint8_t *__restrict__ ray_mask,
-                                                      double rejection, double decay, int64_t nrows,
-                                                      double *__restrict__ fidelity, double *__restrict__ residual)
+// (a node takes the largest of its accepted rows' values in one atomic max)
+__global__ __launch_bounds__(256) void k_br_fidelity(const BlockRows m, const double *__restrict__ x,
+                                                     const double *__restrict__ mismatch, const uint8_t *__restrict__ ray_mask,
+                                                     double rejection, double decay,
+                                                     double *__restrict__ fidelity, double *__restrict__ residual)
 {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= m.num) return;
     const int lane = threadIdx.x & 63;
-    if (ray_mask && !ray_mask[row >> 2]) {
-        if (residual && lane == 0) residual[row] = 0.0;
+    if (ray_mask && !ray_mask[ray]) {
+        if (residual && lane < 4) residual[ray * 4 + lane] = 0.0;
         return;
     }
-    const int64_t b = indptr[row], e = indptr[row + 1];
-    double s = 0;
-    for (int64_t k = b + lane; k < e; k += 64) s = __builtin_fma(data[k], x[indices[k]], s);
-    s = wave_sum_f64(s);
-    const double res = __builtin_fabs(s - mismatch[row]);
-    if (residual && lane == 0) residual[row] = res;
-    if (res < rejection) {
-        const double f = 1 - decay * res;
-        for (int64_t k = b + lane; k < e; k += 64) atomic_max_f64(&fidelity[indices[k]], f);
+    const int64_t b = m.uoff[ray], e = m.uoff[ray + 1];
+    double s[4], f[4];
+    br_dots(m, b, e, lane, x, s);
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double res = __builtin_fabs(s[r] - mismatch[ray * 4 + r]);
+        if (residual && lane == r) residual[ray * 4 + r] = res;
+        const bool acc = res < rejection;
+        f[r] = acc ? 1 - decay * res : -__builtin_inf();
+        any |= acc;
+    }
+    if (!any) return;
+    for (int64_t u = b + lane; u < e; u += 64) {
+        const double2 *p2 = reinterpret_cast<const double2 *>(m.uvals + u * 4);
+        const double2 lo = p2[0], hi = p2[1];
+        double best = -__builtin_inf();
+        if (m.kept(lo.x)) best = f[0];
+        if (m.kept(lo.y) && f[1] > best) best = f[1];
+        if (m.kept(hi.x) && f[2] > best) best = f[2];
+        if (m.kept(hi.y) && f[3] > best) best = f[3];
+        if (best > -__builtin_inf()) atomic_max_f64(&fidelity[m.ucols[u]], best);
     }
 }
 

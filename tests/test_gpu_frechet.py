@@ -128,7 +128,7 @@ def test_forward_operator_golden(ctx, arith):
 
 def test_reconstruction_loop_passes(ctx, orc):
     """SURVEY.md section 8f NEXT-2 (NonObstacle.jl:340-367): dofs, b = M' mismatch over the selected rays,
-    residual + fidelity update, on the device CSR against the numpy restatement in oracle/orc.py."""
+    residual + fidelity update, on the device block rows against the numpy restatement in oracle/orc.py."""
     import ray_amd
     N = 61
     c, tab, m = _data(orc, N, 6, 24, 1)
@@ -165,7 +165,13 @@ def test_reconstruction_loop_passes(ctx, orc):
     # rows within rounding of the threshold may flip; none here by construction of the margin check
     margin = np.min(np.abs(res_ref - rejection))
     assert margin > 1e-12
-    assert np.array_equal(fid, fid_ref)                            # max is order-independent: exact
+    assert np.max(np.abs(fid - fid_ref)) <= 1e-12
+    # and exactly the max over the accepted rows of 1 - decay * (the device's own residual): max is order-independent
+    fid_own = fidelity.copy()
+    for k in rows[res[rows] < rejection]:
+        cols = M.indices[M.indptr[k]:M.indptr[k + 1]]
+        fid_own[cols] = np.maximum(fid_own[cols], 1 - 0.5 * res[k])
+    assert np.array_equal(fid, fid_own)
     assert (fid != fidelity).any()
     F.close()
 
