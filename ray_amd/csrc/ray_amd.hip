@@ -1619,13 +1619,15 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, f->uoff(), &f->U))) return rc;
     HIPCHK(frechet_alloc(f, kFmUcols, sizeof(int32_t) * (size_t)(f->U ? f->U : 1)));
     HIPCHK(frechet_alloc(f, kFmUvals, sizeof(double) * 4 * (size_t)(f->U ? f->U : 1)));
-    // the ray's records sit in LDS during the merge when they fit (48 KiB = 384 rows; RAY_FRECHET_LDS_ROWS for the tests)
+    // the ray's records sit in LDS during the merge when they fit (42 KiB = 224 rows of 144 + 48 B; RAY_FRECHET_LDS_ROWS for the tests)
     const char *env_rows = getenv("RAY_FRECHET_LDS_ROWS");
-    int lds_rows = std::min(frechet_rows(cap_max), 384);
+    int lds_rows = std::min(frechet_rows(cap_max), kMergeLdsMaxRows);
     if (env_rows) lds_rows = std::max(0, std::min(lds_rows, atoi(env_rows)));
-    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)num), dim3(256), (size_t)lds_rows * kTrajDoubles * sizeof(double), ctx->stream,
+    const char *env_grid = getenv("RAY_MERGE_GRID");
+    const int64_t emit_grid = env_grid ? std::max<int64_t>(1, std::min<int64_t>(num, atoi(env_grid))) : num;
+    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes + (getenv("RAY_MERGE_LDS_PAD") ? (size_t)atoi(getenv("RAY_MERGE_LDS_PAD")) : 0), ctx->stream,
                        dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(),
-                       drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, f->ucols(), f->uvals(), f->rowcnt());
+                       drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
     HIPCHK(hipGetLastError());
     HIPCHK(frechet_alloc(f, kFmIndptr, sizeof(int64_t) * (size_t)(4 * num + 1)));
     if ((rc = scan_counts(ctx, f->rowcnt(), 4 * num, f->indptr(), &f->nnz))) return rc;
@@ -2052,6 +2054,17 @@ int ray_debug_stats(unsigned long long out[12])
     unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
+    return RAY_OK;
+}
+#endif
+
+#ifdef RAY_FR_PHASES
+// instrumentation build only: summed phase cycles of k_merge_emit since the last call
+int ray_debug_fr_phases(unsigned long long out[8])
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_phase), sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fr_phase), z, sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     return RAY_OK;
 }
 #endif

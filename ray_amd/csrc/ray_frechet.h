@@ -422,17 +422,18 @@ template <> struct SortKey<uint32_t> {
     static __device__ __forceinline__ uint32_t emission(uint32_t k, int es) { return k & ((1u << es) - 1u); }
 };
 
+// ascending compare-exchange: v_min_u32 + v_max_u32 for the narrow keys
 template <typename K>
-__device__ __forceinline__ void cmp_exchange(K &x, K &y, bool up)
+__device__ __forceinline__ void cmp_exchange(K &x, K &y)
 {
     const K mn = x < y ? x : y, mx = x < y ? y : x;
-    x = up ? mn : mx;
-    y = up ? mx : mn;
+    x = mn;
+    y = mx;
 }
 
-// the compare-exchanges of the strides 2^(nstr-1) .. 1 (in units of the group's own spacing) on eight keys
+// half-cleaners of the strides 2^(nstr-1) .. 1 (in units of the group's own spacing) on eight keys
 template <typename K>
-__device__ __forceinline__ void sort_group_strides(K v[8], int nstr, bool up)
+__device__ __forceinline__ void sort_group_strides(K v[8], int nstr)
 {
 #pragma unroll
     for (int sb = 2; sb >= 0; --sb) {
@@ -440,10 +441,27 @@ __device__ __forceinline__ void sort_group_strides(K v[8], int nstr, bool up)
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int lo = ((p >> sb) << (sb + 1)) | (p & ((1 << sb) - 1));
-                cmp_exchange<K>(v[lo], v[lo | (1 << sb)], up);
+                cmp_exchange<K>(v[lo], v[lo | (1 << sb)]);
             }
         }
     }
+}
+
+// merge of two ascending runs of four (v[0..3], v[4..7]) and, before it, of runs of one and two:
+// the network in its all-ascending form -- the first pass of a stage pairs i with its MIRROR image in the
+// block (i ^ (size - 1)), the rest are plain half-cleaners -- so that no exchange needs a direction.
+template <typename K>
+__device__ __forceinline__ void sort_eight(K v[8])
+{
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) cmp_exchange<K>(v[p], v[p + 1]);                 // size 2
+    cmp_exchange<K>(v[0], v[3]); cmp_exchange<K>(v[1], v[2]);                        // size 4: mirror
+    cmp_exchange<K>(v[4], v[7]); cmp_exchange<K>(v[5], v[6]);
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) cmp_exchange<K>(v[p], v[p + 1]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) cmp_exchange<K>(v[p], v[7 - p]);                     // size 8: mirror
+    sort_group_strides<K>(v, 2);
 }
 
 template <int BT, typename K>
@@ -472,46 +490,61 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     uint32_t *rk = srt + ray_row0(wb, wave_cap[ray >> 6], lane) * kFrSlotsPerCall;
     for (int r = tid; r < nrow; r += BT) s_cell[r] = cells[(wb + r) * 64 + lane];
     __syncthreads();
-    for (int e = tid; e < n2; e += BT) {
-        K key = SK::dead();
-        if (e < ne) {
-            const int r = (int)(((unsigned)e * 43691u) >> 19), k = e - r * kFrSlotsPerCall;     // e / 12 for e < 2^16
-            const int cv = s_cell[r];
-            const int ni = (cv & 0xffff) + stencil_di(k), nj = (cv >> 16) + stencil_dj(k);
-            if (ni >= 0 && ni < N && nj >= 0 && nj < N) key = SK::pack((int64_t)ni + (int64_t)nj * N, e, eshift);
-        }
-        sk[spad(e)] = key;
-    }
-    __syncthreads();
     const int ngroup = n2 >> 3;
-    for (int t = tid; t < ngroup; t += BT) {                       // stages 2, 4, 8 on eight consecutive keys
+    for (int t = tid; t < ngroup; t += BT) {                       // keys of eight consecutive entries; stages 2, 4, 8
         K v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = sk[t * 9 + j];
-#pragma unroll
-        for (int size = 2; size <= 8; size <<= 1)
-#pragma unroll
-            for (int stride = size >> 1; stride > 0; stride >>= 1)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
-                    cmp_exchange<K>(v[lo], v[lo + stride], ((t * 8 + lo) & size) == 0);
-                }
+        for (int j = 0; j < 8; ++j) {
+            const int e = t * 8 + j;
+            v[j] = SK::dead();
+            if (e < ne) {
+                const int r = (int)(((unsigned)e * 43691u) >> 19), k = e - r * kFrSlotsPerCall;     // e / 12 for e < 2^16
+                const int cv = s_cell[r];
+                const int ni = (cv & 0xffff) + stencil_di(k), nj = (cv >> 16) + stencil_dj(k);
+                if (ni >= 0 && ni < N && nj >= 0 && nj < N) v[j] = SK::pack((int64_t)ni + (int64_t)nj * N, e, eshift);
+            }
+        }
+        sort_eight<K>(v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sk[t * 9 + j] = v[j];
     }
     __syncthreads();
-    for (int size = 16, top0 = 3; size <= n2; size <<= 1, ++top0) {
-        for (int top = top0; top >= 0;) {                          // strides 2^top .. 2^b of this stage in one round
-            const int b = top >= 2 ? top - 2 : 0;
+    for (int top0 = 3; (1 << top0) < n2; ++top0) {                 // stage size = 2^(top0 + 1)
+        {   // first round: the mirror pass and the strides 2^(top0-1), 2^(top0-2); a thread's four upper keys sit at
+            // the complemented low bits, which puts every mirror pair (j, 7 - j) into one thread
+            const int b = top0 - 2, lm = (1 << b) - 1;
+            unsigned d[8];                                          // uniform: spad(j << b) in bytes
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
             for (int t = tid; t < ngroup; t += BT) {
-                const int base = ((t >> b) << (b + 3)) | (t & ((1 << b) - 1));
+                const int hi = (t >> b) << (b + 3), lo = t & lm;
+                const unsigned a_lo = (unsigned)sizeof(K) * (unsigned)spad(hi | lo), a_hi = (unsigned)sizeof(K) * (unsigned)spad(hi | (lo ^ lm));
+                char *base = reinterpret_cast<char *>(sk);
                 K v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = sk[spad(base | (j << b))];
-                sort_group_strides<K>(v, top - b + 1, (base & size) == 0);
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<K *>(base + (j < 4 ? a_lo : a_hi) + d[j]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sk[spad(base | (j << b))] = v[j];
+                for (int p = 0; p < 4; ++p) cmp_exchange<K>(v[p], v[7 - p]);
+                sort_group_strides<K>(v, 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<K *>(base + (j < 4 ? a_lo : a_hi) + d[j]) = v[j];
+            }
+            __syncthreads();
+        }
+        for (int top = top0 - 3; top >= 0;) {                      // half-cleaners 2^top .. 2^b in one round
+            const int b = top >= 2 ? top - 2 : 0;
+            unsigned d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
+            for (int t = tid; t < ngroup; t += BT) {
+                const unsigned a0 = (unsigned)sizeof(K) * (unsigned)spad(((t >> b) << (b + 3)) | (t & ((1 << b) - 1)));
+                char *base = reinterpret_cast<char *>(sk);
+                K v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<K *>(base + a0 + d[j]);
+                sort_group_strides<K>(v, top - b + 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<K *>(base + a0 + d[j]) = v[j];
             }
             __syncthreads();
             top = b - 1;
@@ -544,10 +577,12 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
 }
 
 // Theta column of emission e = 12 row + k from the ray's trajectory records (see kTrajDoubles)
-__device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, unsigned e, int N, double th[4], int &node)
+// (`stride`: doubles between consecutive records: kTrajDoubles in the slab, kTrajLdsDoubles in the LDS copy)
+constexpr int kTrajLdsDoubles = kTrajDoubles + 2;      // 144-byte rows: records of different rows on different banks
+__device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, int stride, unsigned e, int N, double th[4], int &node)
 {
     const unsigned r = (e * 43691u) >> 19, k = e - r * (unsigned)kFrSlotsPerCall;
-    const double2 *rec = reinterpret_cast<const double2 *>(recs + (size_t)r * kTrajDoubles);
+    const double2 *rec = reinterpret_cast<const double2 *>(recs + (size_t)r * stride);
     const double2 uv = rec[6];
     const int cv = (int)__double_as_longlong(rec[7].x);
     node = ((cv & 0xffff) + stencil_di((int)k)) + ((cv >> 16) + stencil_dj((int)k)) * N;
@@ -573,88 +608,161 @@ __device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, 
     }
 }
 
+// Tiles of 256 sorted entries: every thread rebuilds ONE entry's Theta column (no divergence: heads and
+// followers cost the same), the tile's columns go to LDS, then each head adds up its run from there (a run
+// that leaves the tile is finished from the records directly), applies rho and stores its node.
+// LDS = true: the ray's records (144-byte rows) and its sorted words were copied to dynamic shared memory;
+// the loop then holds no global load, so nothing in it waits for the stores of the tile before (loads and
+// stores share one in-order counter on gfx9: a load behind a store waits for the store's acknowledgement).
+template <bool LDS>
+__device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, const double *__restrict__ recs_g, int nrow, int ne, int N,
+                                           const double R[16], double droptol, int64_t off, int32_t *__restrict__ ucols,
+                                           double *__restrict__ uvals, int cnt[4])
+{
+    __shared__ double2 s_th[256 * 2];
+    __shared__ uint32_t s_w[256];
+    const int tid = threadIdx.x;
+    const double *recs = LDS ? reinterpret_cast<const double *>(ray_smem) : recs_g;
+    const uint32_t *rk = LDS ? reinterpret_cast<const uint32_t *>(ray_smem + (size_t)nrow * kTrajLdsDoubles * 8) : rk_g;
+    const int stride = LDS ? kTrajLdsDoubles : kTrajDoubles;
+    for (int t0 = 0; t0 < ne; t0 += 256) {
+        const int e = t0 + tid;
+        const uint32_t w = e < ne ? rk[e] : kSrtDead;
+        double s[4] = {0, 0, 0, 0};
+        int node = 0;
+#ifndef RAY_ABL_NOTHETA
+        if (w != kSrtDead) theta_of_entry(recs, stride, w & 0x3FFFu, N, s, node);
+#else
+        s[0] = (double)w; node = 0;
+#endif
+        if (!LDS) s_w[tid] = w;
+        s_th[tid * 2] = make_double2(s[0], s[1]);
+        s_th[tid * 2 + 1] = make_double2(s[2], s[3]);
+        __syncthreads();
+        unsigned kept = 0;                                                                   // bit i: row i keeps this head's entry
+        if (w != kSrtDead && (w & 0x4000u)) {                                                // a head
+#ifndef RAY_ABL_NORUN
+            for (int e2 = e + 1; e2 < ne; ++e2) {
+                const int q = e2 - t0;
+                const uint32_t w2 = (LDS || q >= 256) ? rk[e2] : s_w[q];
+                if (w2 == kSrtDead || (w2 & 0x4000u)) break;
+                double th[4];
+                if (q < 256) {
+                    const double2 lo = s_th[q * 2], hi = s_th[q * 2 + 1];
+                    th[0] = lo.x; th[1] = lo.y; th[2] = hi.x; th[3] = hi.y;
+                } else {
+                    int n2_;
+                    theta_of_entry(recs, stride, w2 & 0x3FFFu, N, th, n2_);
+                }
+                s[0] += th[0]; s[1] += th[1]; s[2] += th[2]; s[3] += th[3];                  // Phi += Theta (:159,175)
+            }
+#endif
+            const int64_t u = off + (int64_t)(w >> 15);
+            double o4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
+                o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
+                kept |= (unsigned)((droptol < 0) || (__builtin_fabs(o4[i]) > droptol)) << i;     // droptol! (:242)
+            }
+#ifdef RAY_ABL_NOSTORE
+            if (o4[0] == 1.2345e300)
+#endif
+            {
+            ucols[u] = (int32_t)node;
+            double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
+            dst[0] = make_double2(o4[0], o4[1]);
+            dst[1] = make_double2(o4[2], o4[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cnt[i] += __popcll(__ballot((kept >> i) & 1u));          // the WAVE's counts, in every lane
+        __syncthreads();
+    }
+}
+
 // sums every distinct node's contributions in emission order, applies rho, writes the ray's block row
 // (ucols, uvals[4]) at uoff[ray] and the per-matrix-row entry counts that survive droptol.
-// The ray's records sit in LDS when they fit `lds_rows` (dynamic shared memory), else they are read in place.
+// Rays of at most `lds_rows` records go through the LDS form of emit_tiles (dynamic shared memory:
+// lds_rows * kMergeLdsRowBytes), longer ones read records and sorted words in place.
+#ifdef RAY_FR_PHASES
+__device__ unsigned long long g_fr_phase[8];     // k_merge_emit: [0] workgroups, [1..4] summed cycles of meta / copy / tiles / tail
+#define RAY_FR_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_fr_phase[k], t_ - t_mark); t_mark = t_; } } while (0)
+#else
+#define RAY_FR_MARK(k) do { } while (0)
+#endif
+constexpr int kMergeLdsRowBytes = kTrajLdsDoubles * 8 + kFrSlotsPerCall * 4;
+constexpr int kMergeLdsMaxRows = 224;           // 42 KiB; 7 record pieces and 11 sorted words per thread in flight
 __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__ srt, const double *__restrict__ traj,
                                                     const int64_t *__restrict__ wave_base, const int32_t *__restrict__ wave_cap,
                                                     const int32_t *__restrict__ nsteps,
                                                     const double *__restrict__ rho, const int64_t *__restrict__ uoff,
-                                                    double droptol, int N, int lds_rows, int32_t *__restrict__ ucols,
+                                                    double droptol, int N, int lds_rows, int64_t num, int32_t *__restrict__ ucols,
                                                     double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
 {
     __shared__ int s_rows[4];
-    const int64_t ray = blockIdx.x;
     const int tid = threadIdx.x;
+    for (int64_t ray = blockIdx.x; ray < num; ray += gridDim.x) {
+#ifdef RAY_FR_PHASES
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    if (tid == 0) atomicAdd(&g_fr_phase[0], 1ull);
+#endif
     if (tid < 4) s_rows[tid] = 0;
     const int nrow = frechet_rows(nsteps[ray]);
     const int ne = nrow * kFrSlotsPerCall;
     const int64_t row0 = ray_row0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
     const uint32_t *rk = srt + row0 * kFrSlotsPerCall;
     const double *recs = traj + row0 * kTrajDoubles;
-    if (nrow <= lds_rows) {
-        double2 *l2 = reinterpret_cast<double2 *>(ray_smem);
-        const double2 *g2 = reinterpret_cast<const double2 *>(recs);
-        for (int k = tid; k < nrow * (kTrajDoubles / 2); k += 256) l2[k] = g2[k];
-        recs = reinterpret_cast<const double *>(ray_smem);
-    }
-    __syncthreads();
     const int64_t off = uoff[ray];
     double R[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) R[k] = rho[ray * 16 + k];
     int cnt[4] = {0, 0, 0, 0};
-    // Tiles of 256 sorted entries: every thread rebuilds ONE entry's Theta column (no divergence: heads and
-    // followers cost the same), the tile's columns and sorted words go to LDS, then each head adds up its run
-    // from there (a run that leaves the tile is finished from the records directly).
-    __shared__ double2 s_th[256 * 2];
-    __shared__ uint32_t s_w[256];
-    for (int t0 = 0; t0 < ne; t0 += 256) {
-        const int e = t0 + tid;
-        const uint32_t w = e < ne ? rk[e] : kSrtDead;
-        double s[4] = {0, 0, 0, 0};
-        int node = 0;
-        if (w != kSrtDead) theta_of_entry(recs, w & 0x3FFFu, N, s, node);
-        s_w[tid] = w;
-        s_th[tid * 2] = make_double2(s[0], s[1]);
-        s_th[tid * 2 + 1] = make_double2(s[2], s[3]);
-        __syncthreads();
-        if (w != kSrtDead && (w & 0x4000u)) {                                                // a head
-            for (int e2 = e + 1; e2 < ne; ++e2) {
-                const int q = e2 - t0;
-                double th[4];
-                if (q < 256) {
-                    const uint32_t w2 = s_w[q];
-                    if (w2 == kSrtDead || (w2 & 0x4000u)) break;
-                    const double2 lo = s_th[q * 2], hi = s_th[q * 2 + 1];
-                    th[0] = lo.x; th[1] = lo.y; th[2] = hi.x; th[3] = hi.y;
-                } else {
-                    const uint32_t w2 = rk[e2];
-                    if (w2 == kSrtDead || (w2 & 0x4000u)) break;
-                    int n2_;
-                    theta_of_entry(recs, w2 & 0x3FFFu, N, th, n2_);
-                }
-                s[0] += th[0]; s[1] += th[1]; s[2] += th[2]; s[3] += th[3];                  // Phi += Theta (:159,175)
-            }
-            const int64_t u = off + (int64_t)(w >> 15);
-            double o4[4];
+#ifdef RAY_FR_PHASES
+    if (R[0] == 1.2345e300 || off < 0 || ne < 0) return;      // the loads above are complete when the mark is taken
+#endif
+    RAY_FR_MARK(1);
+    if (nrow <= lds_rows) {
+        // every load of the copy is issued before the first one is waited for (fixed trip counts: a loop with a
+        // bound known only at run time comes out as load - wait - store per iteration, one memory latency each)
+        double2 *l2 = reinterpret_cast<double2 *>(ray_smem);
+        const double2 *g2 = reinterpret_cast<const double2 *>(recs);
+        uint32_t *lw = reinterpret_cast<uint32_t *>(ray_smem + (size_t)nrow * kTrajLdsDoubles * 8);
+        constexpr int kRecLoads = kMergeLdsMaxRows * (kTrajDoubles / 2) / 256, kWordLoads = (kMergeLdsMaxRows * kFrSlotsPerCall + 255) / 256;
+        double2 rv[kRecLoads];
+        uint32_t wv[kWordLoads];
+        const int nrec2 = nrow * (kTrajDoubles / 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
-                o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
-                cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);               // droptol! (:242)
-            }
-            ucols[u] = (int32_t)node;
-            double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
-            dst[0] = make_double2(o4[0], o4[1]);
-            dst[1] = make_double2(o4[2], o4[3]);
+        for (int k = 0; k < kRecLoads; ++k) rv[k] = tid + 256 * k < nrec2 ? g2[tid + 256 * k] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < kWordLoads; ++k) wv[k] = tid + 256 * k < ne ? rk[tid + 256 * k] : kSrtDead;
+#pragma unroll
+        for (int k = 0; k < kRecLoads; ++k) {
+            const int q = tid + 256 * k;
+            if (q < nrec2) l2[(q >> 3) * (kTrajLdsDoubles / 2) + (q & 7)] = rv[k];
         }
-        __syncthreads();
-    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (cnt[i]) atomicAdd(&s_rows[i], cnt[i]);
+        for (int k = 0; k < kWordLoads; ++k)
+            if (tid + 256 * k < ne) lw[tid + 256 * k] = wv[k];
+        __syncthreads();
+        RAY_FR_MARK(2);
+        emit_tiles<true>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt);
+    } else {
+        __syncthreads();
+        emit_tiles<false>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt);
+    }
+    RAY_FR_MARK(3);
+    // cnt holds the WAVE's counts (ballots): one LDS atomic per wave and row -- 256 lanes adding to one LDS
+    // word are served one lane at a time and kept the LDS pipeline of the whole CU busy for 17k cycles per ray
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (cnt[i]) atomicAdd(&s_rows[i], cnt[i]);
+    }
     __syncthreads();
     if (tid < 4) rowcnt[ray * 4 + tid] = s_rows[tid];
+    __syncthreads();
+    RAY_FR_MARK(4);
+    }
 }
 
 // CSR rows 4*ray + r from the ray's block row; one wave per (ray, r), order kept (columns sorted).

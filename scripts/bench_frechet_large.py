@@ -31,8 +31,16 @@ def main():
         t_all = time.perf_counter() - t0
         cnt = ctx.counters(); ctx.enable_timing(False)
         rows, cols, nnz = F.shape[0], F.shape[1], F.nnz
-        y = F.matvec(np.ones(cols))
+        # RAY_BENCH_NOMATVEC: ablation builds leave columns unwritten; nothing may read the matrix then
+        y = np.zeros(1) if os.environ.get("RAY_BENCH_NOMATVEC") else F.matvec(np.ones(cols))
         F.close()
+        if hasattr(ctx._lib, "ray_debug_fr_phases"):          # instrumentation build (-DRAY_FR_PHASES)
+            import ctypes as C
+            ph = (C.c_ulonglong * 8)()
+            ctx._lib.ray_debug_fr_phases(ph)
+            n = max(ph[0], 1)
+            print(json.dumps({"merge_emit_phases_cycles_per_workgroup": {"workgroups": ph[0], "meta": ph[1] / n, "copy": ph[2] / n,
+                                                                          "tiles": ph[3] / n, "tail": ph[4] / n}}), flush=True)
         print(json.dumps({"workload": f"ScatterForwardOperator {ns}x{nd} rays, N={N}, dt={dt}", "call": rep,
                           "rays": int(m.shape[0]), "ray_steps": int(info["nsteps"].sum()), "nnz": int(nnz),
                           "csr_GB": nnz * 12 / 1e9, "kernel_ms": cnt["kernel_ms"], "launches": cnt["launches"],

@@ -67,6 +67,15 @@ class DevBuf:
             pass
 
 
+def download(ptr, count, dtype):
+    """count elements of dtype from the device address `ptr` (blocking copy: waits for the device)."""
+    out = np.empty(count, dtype=dtype)
+    if out.nbytes:
+        _ok(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")
+        _ok(hip().hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), D2H), "hipMemcpy D2H")
+    return out
+
+
 def stream_create(nonblocking=True):
     s = C.c_void_p()
     _ok(hip().hipStreamCreateWithFlags(C.byref(s), C.c_uint(1 if nonblocking else 0)), "hipStreamCreateWithFlags")

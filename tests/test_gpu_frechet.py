@@ -190,6 +190,41 @@ def test_forward_operator_chunked_equals_single(ctx, orc, monkeypatch):
     assert np.array_equal(i1["nsteps"], i2["nsteps"]) and np.array_equal(i1["status"], i2["status"])
 
 
+@pytest.mark.parametrize("lds_rows", [0, 20])
+def test_forward_operator_merge_paths_agree(ctx, orc, monkeypatch, lds_rows):
+    """k_merge_emit keeps a ray's records and sorted entries in LDS when they fit and reads them in place
+    otherwise (rays of more than 224 steps): identical matrix either way (RAY_FRECHET_LDS_ROWS caps the LDS form;
+    at 20 the rays of this case split between the two forms); block rows against the exported CSR."""
+    import ray_amd
+    import hiprt
+    c, tab, m = _data(orc, 61, 6, 40, 1, bump=0.3)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
+    assert i1["nsteps"].min() < 19 < i1["nsteps"].max()
+    monkeypatch.setenv("RAY_FRECHET_LDS_ROWS", str(lds_rows))
+    F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 2e-2, ctx=ctx, droptol=1e-12)
+    M2 = F.tocsr()
+    assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
+    assert np.array_equal(M1.data, M2.data)
+    # the device-resident block rows hold the same matrix: per ray the union of its four rows' columns
+    n, uoff_p, ucols_p, uvals_p = F.block_rows_dev()
+    num = m.shape[0]
+    uoff = hiprt.download(uoff_p, num + 1, np.int64)
+    ucols = hiprt.download(ucols_p, n, np.int32)
+    uvals = hiprt.download(uvals_p, 4 * n, np.float64).reshape(n, 4)
+    assert uoff[0] == 0 and uoff[-1] == n and np.all(np.diff(uoff) >= 0)
+    D = M2.toarray()
+    for j in (0, 7, num // 2, num - 1):
+        cols = ucols[uoff[j]:uoff[j + 1]]
+        assert np.all(np.diff(cols) > 0)
+        vals = uvals[uoff[j]:uoff[j + 1]]
+        kept = np.where(np.abs(vals) > 1e-12, vals, 0.0)
+        blk = np.zeros((4, D.shape[1]))
+        blk[:, cols] = kept.T
+        assert np.array_equal(blk, D[4 * j:4 * j + 4])
+    F.close()
+
+
 @pytest.mark.parametrize("N,ns,nd,dt", [(61, 6, 40, 2e-2), (75, 3, 70, 2e-2)])
 def test_forward_operator_sort_key_widths_agree(ctx, orc, monkeypatch, N, ns, nd, dt):
     """k_merge_sort runs on 32-bit keys when node and emission index fit together and on 64-bit keys
