@@ -617,10 +617,8 @@ __device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, 
 template <bool LDS>
 __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, const double *__restrict__ recs_g, int nrow, int ne, int N,
                                            const double R[16], double droptol, int64_t off, int32_t *__restrict__ ucols,
-                                           double *__restrict__ uvals, int cnt[4])
+                                           double *__restrict__ uvals, int cnt[4], double2 *s_th, uint32_t *s_w)
 {
-    __shared__ double2 s_th[256 * 2];
-    __shared__ uint32_t s_w[256];
     const int tid = threadIdx.x;
     const double *recs = LDS ? reinterpret_cast<const double *>(ray_smem) : recs_g;
     const uint32_t *rk = LDS ? reinterpret_cast<const uint32_t *>(ray_smem + (size_t)nrow * kTrajLdsDoubles * 8) : rk_g;
@@ -643,12 +641,12 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
         if (w != kSrtDead && (w & 0x4000u)) {                                                // a head
 #ifndef RAY_ABL_NORUN
             for (int e2 = e + 1; e2 < ne; ++e2) {
-                const int q = e2 - t0;
+                const int q = e2 - t0, qc = q < 256 ? q : 255;
                 const uint32_t w2 = (LDS || q >= 256) ? rk[e2] : s_w[q];
+                const double2 lo = s_th[qc * 2], hi = s_th[qc * 2 + 1];                      // read with the word: one LDS latency per follower
                 if (w2 == kSrtDead || (w2 & 0x4000u)) break;
                 double th[4];
                 if (q < 256) {
-                    const double2 lo = s_th[q * 2], hi = s_th[q * 2 + 1];
                     th[0] = lo.x; th[1] = lo.y; th[2] = hi.x; th[3] = hi.y;
                 } else {
                     int n2_;
@@ -700,6 +698,8 @@ __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__
                                                     double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
 {
     __shared__ int s_rows[4];
+    __shared__ double2 s_th[256 * 2];            // the tile's Theta columns
+    __shared__ uint32_t s_w[256];                // the tile's sorted words (form without the LDS copy)
     const int tid = threadIdx.x;
     for (int64_t ray = blockIdx.x; ray < num; ray += gridDim.x) {
 #ifdef RAY_FR_PHASES
@@ -745,10 +745,10 @@ __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__
             if (tid + 256 * k < ne) lw[tid + 256 * k] = wv[k];
         __syncthreads();
         RAY_FR_MARK(2);
-        emit_tiles<true>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt);
+        emit_tiles<true>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt, s_th, s_w);
     } else {
         __syncthreads();
-        emit_tiles<false>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt);
+        emit_tiles<false>(rk, recs, nrow, ne, N, R, droptol, off, ucols, uvals, cnt, s_th, s_w);
     }
     RAY_FR_MARK(3);
     // cnt holds the WAVE's counts (ballots): one LDS atomic per wave and row -- 256 lanes adding to one LDS
