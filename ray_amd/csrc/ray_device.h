@@ -65,7 +65,12 @@ __device__ __forceinline__ double div6(double a)
 // a nearby position (the next RK4 stage moves a ray by ~1e-4 of a cell) finds its record there
 // without a new fetch.
 constexpr int kRunSlots = 64;                       // record slots per wave: one per lane, never overflows
-constexpr int kPasses = 6;                          // global_load_lds passes that fill them (6 x 1 KiB = 64 x 96 B)
+#ifndef RAY_SLOT_PIECES
+#define RAY_SLOT_PIECES 6                           // 16-byte pieces per record slot: 6 = packed 96-byte slots; 7 = 112-byte
+#endif                                              // slots (the seventh piece is never loaded): 16 bank positions instead of 8
+constexpr int kSlotPieces = RAY_SLOT_PIECES;
+constexpr unsigned kSlotBytes = 16u * kSlotPieces;
+constexpr int kPasses = kSlotPieces;                // global_load_lds passes that fill them (P x 1 KiB = 64 slots x 16 P bytes)
 constexpr int kWaveSlotBytes = kPasses * 1024;
 constexpr int kTagEntries = 128;                    // per wave, 4 bytes each: (cell id << 6) | slot, or kTagEmpty
 constexpr unsigned kTagEmpty = 0xffffffffu;
@@ -147,10 +152,12 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     asm volatile("" : "+v"(a.wrec_v), "+v"(a.nb_v));       // opaque: not re-materialised from SGPRs per use
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
-        const unsigned v = a.lane + (sl == 0 ? 0u : sl == 1 ? 4u : 2u), run = (v * 171u) >> 10;   // v / 6
+        const unsigned v = a.lane + (kSlotPieces == 6 ? (sl == 0 ? 0u : sl == 1 ? 4u : 2u) : (unsigned)sl);
+        const unsigned run = kSlotPieces == 6 ? (v * 171u) >> 10 : (v * 147u) >> 10;              // v / 6, v / 7
         a.role_run4[sl] = run * 4u;
-        a.role_poff[sl] = (v - run * 6u) * 16u;
+        a.role_poff[sl] = (v - run * (unsigned)kSlotPieces) * 16u;
     }
+    static_assert(kSlotPieces == 6 || kSlotPieces == 7, "slot pieces");
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
     lds_st_u32(a.wcells + a.lane * 4u, 0u);
     lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
@@ -177,19 +184,37 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c)   
 // Loader roles.  In pass t lane l handles piece q = 64t + l: run q/6, 16-byte piece q%6.  Because
 // 64 = 6*10 + 4, q = 6*base_t + sh_t + l with sh_t = 4t mod 6 = 0,4,2,0,4,2 and base_t = 0,10,21,32,
 // 42,53: only three role patterns exist (slot t%3), the pass enters as a constant run offset.
-__device__ __forceinline__ constexpr unsigned pass_shift(int t) { return (4u * t) % 6u; }
-__device__ __forceinline__ constexpr unsigned pass_base(int t) { return (64u * t - (4u * t) % 6u) / 6u; }
+__device__ __forceinline__ constexpr unsigned pass_shift(int t) { return (64u * t) % (unsigned)kSlotPieces; }
+__device__ __forceinline__ constexpr unsigned pass_base(int t) { return (64u * t - (64u * t) % (unsigned)kSlotPieces) / (unsigned)kSlotPieces; }
+
+// role of this lane in pass T: run (times 4) and byte offset of its piece; 6-piece slots keep the three patterns in
+// registers, 7-piece slots (seven patterns) compute them (v / 7 = v * 147 >> 10 for v < 77)
+template <int T>
+__device__ __forceinline__ void pass_role(const GridAcc &a, unsigned &run4, unsigned &poff)
+{
+    if (kSlotPieces == 6) { run4 = a.role_run4[T % 3]; poff = a.role_poff[T % 3]; return; }
+    if (T < 2) { run4 = a.role_run4[T]; poff = a.role_poff[T]; return; }           // the common two passes: kept
+    unsigned l = a.lane;
+    asm volatile("" : "+v"(l));                      // computed where it is used (rare passes), not hoisted into live registers
+    const unsigned v = l + pass_shift(T), run = (v * 147u) >> 10;
+    run4 = run * 4u;
+    poff = (v - run * 7u) * 16u;
+}
 
 template <int T>
 __device__ __forceinline__ unsigned read_cell_of_pass(const GridAcc &a)
 {
-    return lds_ld_u32(a.wcells + a.role_run4[T % 3] + 4u * pass_base(T));
+    unsigned run4, poff;
+    pass_role<T>(a, run4, poff);
+    return lds_ld_u32(a.wcells + run4 + 4u * pass_base(T));
 }
 template <int T>
 __device__ __forceinline__ void dma_pass(const char *rec, const GridAcc &a, unsigned c, unsigned npiece)
 {
-    if (a.lane + 64u * T < npiece)
-        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, a.role_poff[T % 3])),
+    unsigned run4, poff;
+    pass_role<T>(a, run4, poff);
+    if (a.lane + 64u * T < npiece && (kSlotPieces == 6 || poff < 96u))
+        __builtin_amdgcn_global_load_lds((gptr_t)(rec + mad24(c, 96u, poff)),
                                          (lptr_t)RAY_LDS_PTR(char, a.wrec + T * 1024u), 16, 0, 0);
 }
 
@@ -224,7 +249,7 @@ __device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a,
     const bool leader = left != cid;
     const unsigned long long mask = __ballot(leader);
     const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
-    const unsigned npiece = 6u * (unsigned)(__builtin_popcount(mlo) + __builtin_popcount(mhi));   // uniform, >= 6
+    const unsigned npiece = (unsigned)kSlotPieces * (unsigned)(__builtin_popcount(mlo) + __builtin_popcount(mhi));   // uniform
     // run index of this lane = leaders at or below it, minus one = set bits of (mask >> 1) below it
     // (bit 0 is always set)
     const unsigned long long m1 = mask >> 1;
@@ -265,6 +290,11 @@ __device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a,
             asm volatile("" : "+v"(c4), "+v"(c5));
             dma_pass<4>(rec, a, c4, npiece);
             dma_pass<5>(rec, a, c5, npiece);
+            if (kSlotPieces == 7 && npiece > 384u) {
+                unsigned c6 = read_cell_of_pass<6>(a);
+                asm volatile("" : "+v"(c6));
+                dma_pass<6>(rec, a, c6, npiece);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -278,7 +308,7 @@ __device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a,
     return;
 #endif
     rs.cid = cid;
-    rs.addr = mad24(rank, 96u, a.wrec_v);
+    rs.addr = mad24(rank, kSlotBytes, a.wrec_v);
     asm volatile("" : "+v"(rs.addr));            // computed once: the look-up after this fetch reuses the register
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = lds_ld_d2(rs.addr + 16u * k);
@@ -305,7 +335,7 @@ __device__ __forceinline__ void lookup_records(const char *rec, const GridAcc &a
     const unsigned d = tag - ((unsigned)cid << 6);           // = slot on a hit, >= 64 otherwise (kTagEmpty included)
     const bool hit = d < 64u;
     const unsigned slot = d & 63u;                           // a missing lane reads some slot and overwrites it below
-    const unsigned saddr = mad24(slot, 96u, a.wrec_v);
+    const unsigned saddr = mad24(slot, kSlotBytes, a.wrec_v);
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[k] = lds_ld_d2(saddr + 16u * k);
 #ifdef RAY_STATS

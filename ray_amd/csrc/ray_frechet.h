@@ -473,7 +473,7 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     typedef SortKey<K> SK;
     auto spad = [](int i) { return i + (i >> 3); };
     K *sk = reinterpret_cast<K *>(ray_smem);
-    __shared__ int s_cnt[BT];
+    __shared__ int s_cnt[BT / 64];
     __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 1];
     const int64_t ray = blockIdx.x;
     const int tid = threadIdx.x;
@@ -493,16 +493,19 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     const int ngroup = n2 >> 3;
     for (int t = tid; t < ngroup; t += BT) {                       // keys of eight consecutive entries; stages 2, 4, 8
         K v[8];
+        // eight consecutive entries lie in at most two records: slot k0 + j of record r0, or slot k0 + j - 12 of r0 + 1
+        const int e0 = t * 8;
+        const int r0 = (int)(((unsigned)e0 * 43691u) >> 19), k0 = e0 - r0 * kFrSlotsPerCall;        // e0 / 12 for e0 < 2^16
+        const int cva = e0 < ne ? s_cell[r0] : 0, cvb = r0 + 1 < nrow ? s_cell[r0 + 1] : 0;
+        const int ia = cva & 0xffff, ja = cva >> 16, ib = cvb & 0xffff, jb = cvb >> 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int e = t * 8 + j;
-            v[j] = SK::dead();
-            if (e < ne) {
-                const int r = (int)(((unsigned)e * 43691u) >> 19), k = e - r * kFrSlotsPerCall;     // e / 12 for e < 2^16
-                const int cv = s_cell[r];
-                const int ni = (cv & 0xffff) + stencil_di(k), nj = (cv >> 16) + stencil_dj(k);
-                if (ni >= 0 && ni < N && nj >= 0 && nj < N) v[j] = SK::pack((int64_t)ni + (int64_t)nj * N, e, eshift);
-            }
+            const bool nxt = k0 + j >= kFrSlotsPerCall;
+            const int k = nxt ? k0 + j - kFrSlotsPerCall : k0 + j;
+            const int ni = (nxt ? ib : ia) + stencil_di(k), nj = (nxt ? jb : ja) + stencil_dj(k);
+            const bool ok = e0 + j < ne && (unsigned)ni < (unsigned)N && (unsigned)nj < (unsigned)N;
+            const K key = SK::pack((int64_t)ni + (int64_t)nj * N, e0 + j, eshift);
+            v[j] = ok ? key : SK::dead();
         }
         sort_eight<K>(v);
 #pragma unroll
@@ -550,29 +553,48 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
             top = b - 1;
         }
     }
-    // rank of each entry's node: heads counted per contiguous chunk, scanned over the BT threads
+    // rank of each entry's node: heads counted per contiguous chunk of n2 / BT keys, scanned over the BT threads
+    // (inclusive scan inside the wave by shuffles, the four wave totals through LDS)
     const int cs = n2 / BT, e0 = tid * cs;
+    const K before = e0 > 0 ? sk[spad(e0 - 1)] : SK::dead();       // dead sorts last: never equal to a live key's node
     int heads = 0;
-    for (int e = e0; e < e0 + cs; ++e) {
-        const K k = sk[spad(e)];
-        heads += k != SK::dead() && (e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift));
+    {
+        uint64_t pn = e0 > 0 && before != SK::dead() ? SK::node(before, eshift) : ~0ull;
+        for (int e = e0; e < e0 + cs; ++e) {
+            const K k = sk[spad(e)];
+            const uint64_t nd = SK::node(k, eshift);
+            heads += k != SK::dead() && nd != pn;
+            pn = nd;
+        }
     }
-    s_cnt[tid] = heads;
+    int incl = heads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 63) s_cnt[tid >> 6] = incl;
     __syncthreads();
-    for (int off = 1; off < BT; off <<= 1) {
-        const int v = tid >= off ? s_cnt[tid - off] : 0;
-        __syncthreads();
-        s_cnt[tid] += v;
-        __syncthreads();
+    int wave_before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) {
+        const int c = s_cnt[w];
+        wave_before += w < (tid >> 6) ? c : 0;
+        total += c;
     }
-    int rank = s_cnt[tid] - heads - 1;              // rank of the last head before this chunk
-    if (tid == BT - 1) ucount[ray] = s_cnt[BT - 1];
-    for (int e = e0; e < e0 + cs; ++e) {
-        const K k = sk[spad(e)];
-        if (k == SK::dead()) { if (e < ne) rk[e] = kSrtDead; continue; }
-        const bool head = e == 0 || SK::node(sk[spad(e - 1)], eshift) != SK::node(k, eshift);
-        rank += head;
-        rk[e] = (uint32_t)rank << 15 | (uint32_t)head << 14 | SK::emission(k, eshift);
+    int rank = wave_before + incl - heads - 1;      // rank of the last head before this chunk
+    if (tid == 0) ucount[ray] = total;
+    {
+        uint64_t pn = e0 > 0 && before != SK::dead() ? SK::node(before, eshift) : ~0ull;
+        for (int e = e0; e < e0 + cs; ++e) {
+            const K k = sk[spad(e)];
+            if (k == SK::dead()) { if (e < ne) rk[e] = kSrtDead; continue; }
+            const uint64_t nd = SK::node(k, eshift);
+            const bool head = nd != pn;
+            pn = nd;
+            rank += head;
+            rk[e] = (uint32_t)rank << 15 | (uint32_t)head << 14 | SK::emission(k, eshift);
+        }
     }
 }
 
