@@ -1549,6 +1549,9 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
         wave_base[(size_t)w] = rows;
         rows += frechet_rows((int)n);
     }
+    std::vector<int32_t> order((size_t)nwave);
+    for (int64_t w = 0; w < nwave; ++w) order[(size_t)w] = (int32_t)w;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cap[(size_t)x] > cap[(size_t)y]; });
     if (frechet_entries(cap_max) > kMergeMaxEntries)
         return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator: more than 1364 steps per ray (T/dt); the per-ray merge holds 16384 stencil entries");
     const size_t slots = (size_t)rows * 64;                  // trajectory records of this call
@@ -1556,7 +1559,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     if (slots * (kTrajBytesPerRow + 12 * 36) + (size_t)num * 512 > free_b + ctx->ws_cap[0] + ctx->ws_cap[1] + ctx->ws_cap[9])
         return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the trajectory slab does not fit in device memory (sum of T/dt too large); split the rays");
-    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7);
+    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), dorder(ctx, 10);
     RayOutBufs ob_(ctx);
     void *ptraj = nullptr, *psrt = nullptr, *pcells = nullptr;
     HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * kTrajDoubles * sizeof(double), &ptraj));
@@ -1568,6 +1571,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(drho.alloc(sizeof(double) * 16 * (size_t)num));
     HIPCHK(dbase.alloc(sizeof(int64_t) * (size_t)nwave));
     HIPCHK(dcap.alloc(sizeof(int32_t) * (size_t)nwave));
+    HIPCHK(dorder.alloc(sizeof(int32_t) * (size_t)nwave));
     HIPCHK(ducnt.alloc(sizeof(int32_t) * (size_t)num));
     HIPCHK(frechet_alloc(f, kFmUoff, sizeof(int64_t) * (size_t)(num + 1)));
     HIPCHK(frechet_alloc(f, kFmRowcnt, sizeof(int32_t) * 4 * (size_t)num));
@@ -1577,18 +1581,19 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
     HIPCHK(hipMemcpyAsync(dbase.p, wave_base.data(), sizeof(int64_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dcap.p, cap.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dorder.p, order.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));           // the host vectors above are read by those copies
 
     FrechetArgs a{};
     a.med = medium_dev(med);
     a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
-    a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>();
+    a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>(); a.wave_order = dorder.as<int32_t>();
     a.traj = dtraj.as<double>(); a.cells = dcells.as<int32_t>();
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
     a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
     a.step_counter = ctx->d_steps;
-    const size_t lds = frechet_lds_bytes(med->N);
+    const size_t lds = frechet_lds_bytes(med->N, ctx->arith != RAY_ARITH_FUSED);
     TimedSpan span(ctx);
     if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
     else hipLaunchKernelGGL(k_frechet<kExact>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
@@ -2043,6 +2048,15 @@ int ray_debug_timeline(unsigned long long *out, int nblocks)
 {
     if (hipDeviceSynchronize() != hipSuccess) return RAY_ERR_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_timeline), sizeof(unsigned long long) * 3 * (size_t)nblocks) != hipSuccess) return RAY_ERR_HIP;
+    return RAY_OK;
+}
+#endif
+
+#ifdef RAY_TIMELINE
+int ray_debug_fr_timeline(unsigned long long *out, int nblocks)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return RAY_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_timeline), sizeof(unsigned long long) * 3 * (size_t)nblocks) != hipSuccess) return RAY_ERR_HIP;
     return RAY_OK;
 }
 #endif

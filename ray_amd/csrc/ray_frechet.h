@@ -153,6 +153,62 @@ __device__ __forceinline__ void rho_stage(const double Jm[16], const double Rin[
     }
 }
 
+// The same stage with rho and the RK4 accumulator in LDS (k_frechet: two waves per SIMD need the 64 VGPRs the two
+// 4x4 arrays would take).  Element pair (2m, 2m+1) of lane l sits at (m * 64 + l) * 16 from `rho_a` / `acc_a`
+// (absolute LDS byte addresses of this lane's column: + m * 1024), so every access is a conflict-free b128.
+// Two columns at a time; operation for operation what rho_stage does.  R (the stage argument) stays in registers.
+__device__ __forceinline__ void lds_st_d2(unsigned addr, double x, double y)
+{
+    lds_d2v v;
+    v.x = x; v.y = y;
+    *RAY_LDS_PTR(lds_d2v, addr) = v;
+}
+template <int MODE>   // 0: acc = V, R = rho + c V; 1: acc += 2 V, R = rho + c V; 2: rho = rho + c (acc + V) where `write`
+__device__ __forceinline__ void rho_stage_lds(const double Jm[16], double R[16], unsigned rho_a, unsigned acc_a, double c, bool write)
+{
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+        double2 rb[4];                                      // rho rows 0..3, columns jp, jp + 1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rb[k] = lds_ld_d2(rho_a + (unsigned)((k * 4 + jp) / 2) * 1024u);
+        double v[4][2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = jp + cc;
+                double t;
+                if (MODE == 0) {
+                    t = Jm[i * 4] * (cc ? rb[0].y : rb[0].x);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) t = __builtin_fma(Jm[i * 4 + k], cc ? rb[k].y : rb[k].x, t);
+                } else {
+                    t = Jm[i * 4] * R[j];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) t = __builtin_fma(Jm[i * 4 + k], R[k * 4 + j], t);
+                }
+                v[i][cc] = t;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned off = (unsigned)((i * 4 + jp) / 2) * 1024u;
+            if (MODE == 0) {
+                lds_st_d2(acc_a + off, v[i][0], v[i][1]);
+                R[i * 4 + jp] = __builtin_fma(v[i][0], c, rb[i].x);
+                R[i * 4 + jp + 1] = __builtin_fma(v[i][1], c, rb[i].y);
+            } else if (MODE == 1) {
+                const double2 ac = lds_ld_d2(acc_a + off);
+                lds_st_d2(acc_a + off, __builtin_fma(2.0, v[i][0], ac.x), __builtin_fma(2.0, v[i][1], ac.y));
+                R[i * 4 + jp] = __builtin_fma(v[i][0], c, rb[i].x);
+                R[i * 4 + jp + 1] = __builtin_fma(v[i][1], c, rb[i].y);
+            } else {
+                const double2 ac = lds_ld_d2(acc_a + off);
+                if (write) lds_st_d2(rho_a + off, __builtin_fma(ac.x + v[i][0], c, rb[i].x), __builtin_fma(ac.y + v[i][1], c, rb[i].y));
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
 {
 #pragma unroll
@@ -203,6 +259,8 @@ struct FrechetArgs {
     double cease_r;
     const int64_t *wave_base;   // record-row offset of every wave (a wave owns 64 x rows records from 64 * base)
     const int32_t *wave_cap;    // step capacity of every wave (rows = cap + 1 records per ray)
+    const int32_t *wave_order;  // workgroup b integrates wave wave_order[b]: longest first (a wave lasts as long as its
+                                // longest ray, 0.3 .. 2.1 ms at 512 x 512 rays, and the chip holds 2048 of 4096 at a time)
     double *traj;               // [wave][lane][row][16] trajectory records (kTrajDoubles)
     int32_t *cells;             // [wave][row][lane] cell of every trajectory node: i | j << 16
     double *X;                  // (num, 4) end states
@@ -243,15 +301,25 @@ __device__ __forceinline__ int stencil_dj(int k) { return (int)((0x0fa5a5u >> (2
 // instruction: the wave transposes through LDS (64 x 144 B, rows padded by 16 B against bank conflicts) and
 // stores 16-byte pieces, 8 consecutive lanes on the 8 pieces of one ray's 128-byte record = one full line.
 // Finished lanes' records are not stored: nobody reads them.
+// LDS of the one-wave workgroup: [ node table, padded to 16 B | rho: 8 planes of 64 x 16 B | RK4 accumulator of rho,
+// same shape ] -- the transposition's staging area lies over the accumulator (dead between stage 4 of a step and
+// stage 1 of the next, which is when a node is emitted) and 1 KB beyond it.
 constexpr int kFrStageBytes = 64 * 144;
-__host__ __device__ inline size_t frechet_lds_bytes(int N) { return (((size_t)N * 8 + 15) & ~(size_t)15) + kFrStageBytes; }
+constexpr int kFrRhoBytes = 8 * 64 * 16;
+__host__ __device__ inline size_t frechet_nodes_bytes(int N, bool nodes) { return nodes ? ((size_t)N * 8 + 15) & ~(size_t)15 : 0; }   // kExact only
+__host__ __device__ inline size_t frechet_lds_bytes(int N, bool nodes) { return frechet_nodes_bytes(N, nodes) + kFrRhoBytes + kFrStageBytes; }
 
 template <int AR>
 __device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4], const PointEval &q, int o,
-                                          const double rho[16], double w,
+                                          unsigned rho_a, double w,
                                           bool live, int64_t wave_base, int64_t wave_row0, int rows, int it, unsigned lane, int &oob)
 {
-    double inv[16];
+    double rho[16], inv[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double2 p2 = lds_ld_d2(rho_a + (unsigned)m * 1024u);
+        rho[2 * m] = p2.x; rho[2 * m + 1] = p2.y;
+    }
     mat4_inv(rho, inv);
     const GridDev &g = a.med.g;
     const double h = g.h;
@@ -261,7 +329,7 @@ __device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4
     const int N = g.N;
     // the stencil reaches i-1 .. i+2, j-1 .. j+2: nodes off the grid are dropped and flagged
     o |= (q.i < 1) | (q.i + 2 >= N) | (q.j < 1) | (q.j + 2 >= N);
-    double2 *stage = reinterpret_cast<double2 *>(ray_smem + (((size_t)N * 8 + 15) & ~(size_t)15));   // [lane][9]
+    double2 *stage = reinterpret_cast<double2 *>(ray_smem + frechet_nodes_bytes(N, AR == kExact) + kFrRhoBytes);   // [lane][9]
     double2 *mine = stage + lane * 9;
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
@@ -274,13 +342,19 @@ __device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4
     const int cellv = q.i | (q.j << 16);
     mine[6] = make_double2(u, v);
     mine[7] = make_double2(__longlong_as_double((long long)cellv), 0.0);
+#ifndef RAY_ABL_NOTRAJ
     a.cells[(wave_base + it) * 64 + lane] = live ? cellv : -1;
+#endif
     const unsigned long long lm = __ballot(live);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                         // 512 pieces, 8 per ray
         const unsigned qq = t * 64 + lane, ray = qq >> 3, part = qq & 7;
+#ifdef RAY_ABL_NOTRAJ
+        if (((lm >> ray) & 1) && w == 1.2345e300) {
+#else
         if ((lm >> ray) & 1) {
+#endif
             const double2 piece = stage[ray * 9 + part];
             *reinterpret_cast<double2 *>(a.traj + (wave_row0 + (int64_t)ray * rows + it) * kTrajDoubles + part * 2) = piece;
         }
@@ -293,14 +367,25 @@ __device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4
 // The reference adds Theta twice per step (:158 before, :174 after) -- the "after" point of step n and
 // the "before" point of step n+1 are the same (X, rho), so one emission per trajectory node carries
 // both weights (trapezoid rule; the cease term :178 joins the last node's weight).
+#ifdef RAY_TIMELINE
+__device__ unsigned long long g_fr_timeline[3 * 65536];   // instrumentation build: start / end clock, hardware id per workgroup
+#endif
 template <int AR>
-__global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
+__global__ __launch_bounds__(64, 2) void k_frechet(const FrechetArgs a)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef RAY_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_fr_timeline[3 * blockIdx.x] = wall_clock64();
+        g_fr_timeline[3 * blockIdx.x + 2] = hw;
+    }
+#endif
+    const int64_t wave = a.wave_order[blockIdx.x];
+    const int64_t r = wave * 64 + threadIdx.x;
     const bool valid = r < a.num;
     const unsigned lane = threadIdx.x & 63;
-    const int64_t wave = r >> 6;
-    {   // node table into LDS (the look-ups read it from there)
+    if (AR == kExact) {   // node table into LDS (the look-ups read it from there; kFused takes its offsets from the cell coordinate)
         double *p_lds = reinterpret_cast<double *>(ray_smem);
         for (int k = threadIdx.x; k < a.med.g.N; k += blockDim.x) p_lds[k] = a.med.g.p[k];
         __syncthreads();
@@ -309,7 +394,10 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
     const int64_t wave_base = a.wave_base[wave], wave_row0 = ray_row0(wave_base, cap, 0);
     const int rows = frechet_rows(cap);
     double X[4] = {0, 0, 1, 0}, T = 0;
-    double rho[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const unsigned rho_a = (unsigned)(uintptr_t)(lptr_t)ray_smem + (unsigned)frechet_nodes_bytes(a.med.g.N, AR == kExact) + lane * 16u;
+    const unsigned acc_a = rho_a + kFrRhoBytes;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds_st_d2(rho_a + (unsigned)m * 1024u, (m == 0 || m == 5) ? 1.0 : 0.0, (m == 2 || m == 7) ? 1.0 : 0.0);
     int steps = 0, st = 0, oob = 0, it = 0;
     if (valid) {
 #pragma unroll
@@ -334,33 +422,33 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
         PointEval q0;
         int o0 = 0;
         point_eval<AR>(a.med.g, X, k1, q0, o0);
-        emit_node<AR>(a, X, q0, o0, rho, wp + dtl * 0.5, active || fin, wave_base, wave_row0, rows, it, lane, oob);
+        emit_node<AR>(a, X, q0, o0, rho_a, wp + dtl * 0.5, active || fin, wave_base, wave_row0, rows, it, lane, oob);
         fin = false;
         if (!anyact) break;                                                  // that was the last node
         // RK4 for X (bit-identical to k_trace) and rho                       :161-172
-        double H[4], Y[4], accx[4], Jm[16], R[16], accr[16];
+        double H[4], Y[4], accx[4], Jm[16], R[16];
         int o = o0;
         const double hdt = 0.5 * dtl;
         jac_from_point(a.med.g, X, q0, Jm, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = k1[k]; Y[k] = (AR == kFused) ? __builtin_fma(k1[k], hdt, X[k]) : X[k] + k1[k] * hdt; }
-        rho_stage<0>(Jm, rho, rho, accr, R, hdt);
+        rho_stage_lds<0>(Jm, R, rho_a, acc_a, hdt, true);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], hdt, X[k]) : X[k] + H[k] * hdt; }
-        rho_stage<1>(Jm, R, rho, accr, R, hdt);
+        rho_stage_lds<1>(Jm, R, rho_a, acc_a, hdt, true);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { accx[k] = __builtin_fma(2.0, H[k], accx[k]); Y[k] = (AR == kFused) ? __builtin_fma(H[k], dtl, X[k]) : X[k] + H[k] * dtl; }
-        rho_stage<1>(Jm, R, rho, accr, R, dtl);
+        rho_stage_lds<1>(Jm, R, rho_a, acc_a, dtl, true);
         hamilton_jac<AR>(a.med.g, Y, H, Jm, o);
         const double dt6 = dtl * 0.16666666666666666;
         if (active) {                          // a finished lane keeps (X, rho) untouched whatever its stages evaluated to
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 X[k] = (AR == kFused) ? __builtin_fma(accx[k] + H[k], dt6, X[k]) : X[k] + div6((accx[k] + H[k]) * dtl);
-            rho_stage<2>(Jm, R, rho, accr, rho, dt6);
         }
+        rho_stage_lds<2>(Jm, R, rho_a, acc_a, dt6, active);
         ++it;
         wp = 0.0;
         if (active) {
@@ -383,12 +471,18 @@ __global__ __launch_bounds__(64) void k_frechet(const FrechetArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k) a.X[r + k * a.ldx] = X[k];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a.rho[r * 16 + k] = rho[k];
+        for (int m = 0; m < 8; ++m) {
+            const double2 p2 = lds_ld_d2(rho_a + (unsigned)m * 1024u);
+            reinterpret_cast<double2 *>(a.rho + r * 16)[m] = p2;
+        }
         a.status[r] = st;
         a.nsteps[r] = steps;
     }
     const unsigned wsum = wave_sum((unsigned)steps);
     if (lane == 0 && a.step_counter) atomicAdd(a.step_counter, (unsigned long long)wsum);
+#ifdef RAY_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_fr_timeline[3 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ---- merge: distinct nodes of one ray --------------------------------------------------------------

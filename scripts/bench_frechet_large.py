@@ -34,6 +34,21 @@ def main():
         # RAY_BENCH_NOMATVEC: ablation builds leave columns unwritten; nothing may read the matrix then
         y = np.zeros(1) if os.environ.get("RAY_BENCH_NOMATVEC") else F.matvec(np.ones(cols))
         F.close()
+        if hasattr(ctx._lib, "ray_debug_fr_timeline"):        # instrumentation build (-DRAY_TIMELINE): k_frechet occupancy
+            import ctypes as C
+            nblk = (int(m.shape[0]) + 63) // 64
+            tl = np.zeros(3 * nblk, dtype=np.uint64)
+            ctx._lib.ray_debug_fr_timeline(tl.ctypes.data_as(C.c_void_p), nblk)
+            tl = tl.reshape(nblk, 3).astype(np.int64)
+            t0, t1 = tl[:, 0].min(), tl[:, 1].max()
+            dur = tl[:, 1] - tl[:, 0]
+            edges = np.linspace(t0, t1, 21)
+            occ = [float(np.mean([(np.minimum(tl[:, 1], hi) - np.maximum(tl[:, 0], lo)).clip(0).sum() / (hi - lo)]))
+                   for lo, hi in zip(edges[:-1], edges[1:])]
+            print(json.dumps({"k_frechet_timeline": {"workgroups": nblk, "span_ticks": int(t1 - t0), "mean_resident": float(dur.sum() / (t1 - t0)),
+                                                      "duration_ticks_min_mean_max": [int(dur.min()), float(dur.mean()), int(dur.max())],
+                                                      "resident_by_twentieth": [round(o) for o in occ],
+                                                      "start_ticks_percentiles_0_50_100": [int(np.percentile(tl[:, 0] - t0, q)) for q in (0, 50, 100)]}}), flush=True)
         if hasattr(ctx._lib, "ray_debug_fr_phases"):          # instrumentation build (-DRAY_FR_PHASES)
             import ctypes as C
             ph = (C.c_ulonglong * 8)()
