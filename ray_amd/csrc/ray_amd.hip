@@ -1628,9 +1628,10 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     const char *env_rows = getenv("RAY_FRECHET_LDS_ROWS");
     int lds_rows = std::min(frechet_rows(cap_max), kMergeLdsMaxRows);
     if (env_rows) lds_rows = std::max(0, std::min(lds_rows, atoi(env_rows)));
+    // one workgroup per ray; RAY_MERGE_GRID (tests, experiments) makes fewer workgroups loop over the rays instead
     const char *env_grid = getenv("RAY_MERGE_GRID");
     const int64_t emit_grid = env_grid ? std::max<int64_t>(1, std::min<int64_t>(num, atoi(env_grid))) : num;
-    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes + (getenv("RAY_MERGE_LDS_PAD") ? (size_t)atoi(getenv("RAY_MERGE_LDS_PAD")) : 0), ctx->stream,
+    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes, ctx->stream,
                        dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(),
                        drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
     HIPCHK(hipGetLastError());

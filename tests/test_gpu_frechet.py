@@ -202,6 +202,8 @@ def test_forward_operator_merge_paths_agree(ctx, orc, monkeypatch, lds_rows):
     M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
     assert i1["nsteps"].min() < 19 < i1["nsteps"].max()
     monkeypatch.setenv("RAY_FRECHET_LDS_ROWS", str(lds_rows))
+    if lds_rows:
+        monkeypatch.setenv("RAY_MERGE_GRID", "7")                 # and seven workgroups looping over the 240 rays
     F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 2e-2, ctx=ctx, droptol=1e-12)
     M2 = F.tocsr()
     assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
