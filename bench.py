@@ -135,8 +135,18 @@ def main():
         c = np.asfortranarray(np.ones_like(c))
     med = ray_amd.GridMedium(c, EXT, ctx)
 
+    # sharding of the (2048 world) x 2048 boundary grid: a COMB of the source circle per rank (sources rank,
+    # rank + world, ...: every rank sees the whole medium, equal work) or a contiguous theta-block (an arc per rank:
+    # the arcs' ray-step counts differ by 16 % on this medium and the step time is the slowest rank's)
     ns_total = NS_PER_GPU * world
-    sb, se = rank * NS_PER_GPU, (rank + 1) * NS_PER_GPU
+    shard = os.environ.get("RAY_BENCH_SHARD", "comb")
+    if shard == "comb":
+        from ray_amd.dist import theta_comb
+        sb, se, stride, cnt_src = theta_comb(ns_total, rank, world)
+        assert cnt_src == NS_PER_GPU
+        ctx.set_option(ray_amd._lib.OPT_SOURCE_STRIDE, stride)
+    else:
+        sb, se = rank * NS_PER_GPU, (rank + 1) * NS_PER_GPU
     num = NS_PER_GPU * ND
     m = torch.empty(9 * num, dtype=torch.float64, device=dev)
     obs = torch.zeros(9 * num, dtype=torch.float64, device=dev)
@@ -228,9 +238,11 @@ def main():
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(cnt["ray_steps"]), float(cnt["rays"])], dtype=torch.float64, device=dev)
+    most = torch.tensor([float(cnt["ray_steps"])], dtype=torch.float64, device=dev)      # the busiest rank's ray-steps
     if world > 1 or force_pg:
         allreduce(el, dist.ReduceOp.MAX)
         allreduce(tot)
+        allreduce(most, dist.ReduceOp.MAX)
     elapsed = float(el.item())
     ray_steps, rays = float(tot[0].item()), float(tot[1].item())
 
@@ -254,7 +266,8 @@ def main():
                                    "reduction" + (" + 1 all-reduce" if world > 1 else ""),
                        "arith": args.arith, "ns_total": ns_total, "nd": ND, "grid": NGRID, "dt": DT,
                        "rays_per_gpu": num, "mean_steps_per_ray": steps_per_launch / num,
-                       "parallelism": f"theta-block x{world}"},
+                       "parallelism": f"theta-{shard} x{world}",
+                       "busiest_rank_over_mean_ray_steps": float(most.item()) * world / ray_steps},
             "roofline": {"bound": "fp64-vector", "kernel": "k_shoot<grid,no-obstacle>",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK, "traffic": traffic,

@@ -92,6 +92,14 @@ int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
  *   RAY_OPT_SKIP_INIT_COLUMNS  ray_shoot_to_exit copies back columns 5..9 only (the caller already holds the
  *                              initial states or does not need them): 44 % fewer bytes over PCIe             */
 #define RAY_OPT_SKIP_INIT_COLUMNS 1
+/*   RAY_OPT_SOURCE_STRIDE      s >= 1 (default 1): ray_shoot_to_exit(_dev) shoots the sources src_begin, src_begin + s,
+ *                              ... below src_end; m has ceil((src_end - src_begin) / s) * nd rows, row i*nd + j is
+ *                              source src_begin + i*s.  Rank r of n with (src_begin, src_end, s) = (r, ns, n) takes a
+ *                              COMB of the source circle instead of an arc: every rank then sees every part of the
+ *                              medium and the ranks' ray-step counts agree to a fraction of a percent, where
+ *                              contiguous theta-blocks differ by 16 % on the shipped medium (no counterpart in the
+ *                              reference, whose workers take whatever @parallel hands them).                      */
+#define RAY_OPT_SOURCE_STRIDE 2
 int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
 /* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by
  * ray_ctx_release_workspaces / ray_ctx_destroy) and copy to / from the caller's arrays.  From pageable memory

@@ -80,6 +80,13 @@ class Context:
 
     def set_option(self, option, value):
         _lib.check(self._lib.ray_ctx_set_option(self.handle, int(option), int(value)))
+        if int(option) == _lib.OPT_SOURCE_STRIDE:
+            self.source_stride = int(value)
+
+    def sources_of_call(self, src_begin, src_end):
+        """Number of sources a shoot of [src_begin, src_end) takes under the context's source stride."""
+        st = getattr(self, "source_stride", 1)
+        return (src_end - src_begin + st - 1) // st
 
     def enable_timing(self, on=True):
         _lib.check(self._lib.ray_ctx_enable_timing(self.handle, int(bool(on))))
@@ -371,7 +378,7 @@ def _resolve(c, gradc, ctx):
 
 def _shoot(med, ob, ns, nd, dt, dir_, time_unit, ctx, src_begin, src_end, max_steps, info):
     src_end = ns if src_end is None else src_end
-    num = (src_end - src_begin) * nd
+    num = (ctx or default_context()).sources_of_call(src_begin, src_end) * nd
     m = np.zeros((num, 9), dtype=np.float64, order="F")
     st = np.zeros(num, dtype=np.int32)
     nst = np.zeros(num, dtype=np.int32)

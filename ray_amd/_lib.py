@@ -14,6 +14,7 @@ TRACE_SHORTEN_CEASE, TRACE_OVERSHOOT = 0, 1
 ARITH_EXACT, ARITH_FUSED = 0, 1
 STREAM_OWN, STREAM_BORROWED = 0, 1
 OPT_SKIP_INIT_COLUMNS = 1
+OPT_SOURCE_STRIDE = 2
 
 
 class RayError(RuntimeError):

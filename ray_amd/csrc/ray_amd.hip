@@ -627,6 +627,7 @@ struct ray_ctx {
     void *ws[kWs] = {};
     size_t ws_cap[kWs] = {};
     bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
+    int src_stride = 1;                        // RAY_OPT_SOURCE_STRIDE
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
     static constexpr int kPool = 7;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows)
@@ -748,21 +749,21 @@ static void drain_timing(ray_ctx *ctx)
 // reconstruction loop / sweep that re-shoots the same grid uploads nothing.
 struct InitTables {
     DevBuf src, cs, sn, dir;
-    int ns = -1, nd = -1, b = -1, e = -1;
+    int ns = -1, nd = -1, b = -1, e = -1, stride = 1;
     double lo = 0, hi = 0;
-    bool matches(const ray_shoot_params *p) const
+    bool matches(const ray_shoot_params *p, int st) const
     {
-        return ns == p->ns && nd == p->nd && b == p->src_begin && e == p->src_end && lo == p->dir_lo && hi == p->dir_hi;
+        return ns == p->ns && nd == p->nd && b == p->src_begin && e == p->src_end && stride == st && lo == p->dir_lo && hi == p->dir_hi;
     }
     int upload(ray_ctx *ctx, const ray_shoot_params *p)
     {
-        const int nloc = p->src_end - p->src_begin;
+        const int st = ctx->src_stride, nloc = (p->src_end - p->src_begin + st - 1) / st;
         std::vector<double> source(p->ns + 1), direct(p->nd + 2);
         hostmath::linspace(0.0, 2 * M_PI, p->ns + 1, source.data());      // NonObstacle.jl:55
         hostmath::linspace(p->dir_lo, p->dir_hi, p->nd + 2, direct.data()); // NonObstacle.jl:56
         std::vector<double> s(nloc), c(nloc), sn_(nloc);
         for (int i = 0; i < nloc; ++i) {
-            s[i] = source[p->src_begin + i];
+            s[i] = source[p->src_begin + i * st];
             c[i] = std::cos(s[i]);                                        // NonObstacle.jl:57
             sn_[i] = std::sin(s[i]);
         }
@@ -775,14 +776,14 @@ struct InitTables {
         HIPCHK(hipMemcpyAsync(sn.p, sn_.data(), sizeof(double) * nloc, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(dir.p, direct.data() + 1, sizeof(double) * p->nd, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        ns = p->ns; nd = p->nd; b = p->src_begin; e = p->src_end; lo = p->dir_lo; hi = p->dir_hi;
+        ns = p->ns; nd = p->nd; b = p->src_begin; e = p->src_end; stride = st; lo = p->dir_lo; hi = p->dir_hi;
         return RAY_OK;
     }
 };
 
 static int init_tables(ray_ctx *ctx, const ray_shoot_params *p, InitTables **out)
 {
-    if (ctx->init && ctx->init->matches(p)) { *out = ctx->init; return RAY_OK; }
+    if (ctx->init && ctx->init->matches(p, ctx->src_stride)) { *out = ctx->init; return RAY_OK; }
     HIPCHK(hipStreamSynchronize(ctx->stream));          // a launch may still read the old tables
     delete ctx->init;
     ctx->init = new InitTables;
@@ -1172,17 +1173,23 @@ static int check_params(const ray_shoot_params *p)
     return RAY_OK;
 }
 
+// sources of a call: src_begin, src_begin + stride, ... below src_end (RAY_OPT_SOURCE_STRIDE of the context)
+static int call_sources(const ray_ctx *ctx, const ray_shoot_params *prm)
+{
+    return (prm->src_end - prm->src_begin + ctx->src_stride - 1) / ctx->src_stride;
+}
+
 static int shoot_to_exit_impl(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
                               const ray_shoot_params *prm, double *m_dev, int64_t ld,
                               int32_t *status, int32_t *nsteps, int32_t *nreflect)
 {
-    const int64_t num = (int64_t)(prm->src_end - prm->src_begin) * prm->nd;
+    const int64_t num = (int64_t)call_sources(ctx, prm) * prm->nd;
     if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
     InitTables *tab = nullptr;
     int rc = init_tables(ctx, prm, &tab);
     if (rc) return rc;
     ShootArgs a{};
-    a.init = 1; a.nd = prm->nd; a.nsrc = prm->src_end - prm->src_begin;
+    a.init = 1; a.nd = prm->nd; a.nsrc = call_sources(ctx, prm);
     a.src = tab->src.as<double>(); a.src_cos = tab->cs.as<double>(); a.src_sin = tab->sn.as<double>();
     a.direct = tab->dir.as<double>();
     a.half_pi = M_PI * 0.5;
@@ -1246,7 +1253,7 @@ int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *o
     if (rc) return rc;
     if ((rc = check_med(ctx, med)) || (rc = check_params(prm))) return rc;
     if (!m_host) return fail(RAY_ERR_INVALID, "null m");
-    const int64_t num = (int64_t)(prm->src_end - prm->src_begin) * prm->nd;
+    const int64_t num = (int64_t)call_sources(ctx, prm) * prm->nd;
     if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
     if (num == 0) return RAY_OK;
     WsBuf dm(ctx, kWsM);
@@ -2151,6 +2158,11 @@ int ray_ctx_set_option(ray_ctx *ctx, int option, int value)
 {
     if (!ctx) return fail(RAY_ERR_INVALID, "null context");
     if (option == RAY_OPT_SKIP_INIT_COLUMNS) { ctx->skip_init_cols = value != 0; return RAY_OK; }
+    if (option == RAY_OPT_SOURCE_STRIDE) {
+        if (value < 1) return fail(RAY_ERR_INVALID, "source stride must be >= 1");
+        ctx->src_stride = value;
+        return RAY_OK;
+    }
     return fail(RAY_ERR_INVALID, "unknown option");
 }
 

@@ -23,6 +23,16 @@ def theta_block(ns, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def theta_comb(ns, rank, world):
+    """Comb sharding: `rank` owns the sources rank, rank + world, ... < ns -- (src_begin, src_end, stride, count) for
+    ray_amd's RAY_OPT_SOURCE_STRIDE.  Every rank sweeps the whole source circle at 1/world of its density, so the
+    ranks' ray-step counts agree closely whatever the medium's asymmetry (contiguous theta-blocks of the shipped
+    medium differ by 16 %, which a max-over-ranks step time pays in full)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return rank, ns, world, (ns - rank + world - 1) // world
+
+
 def allreduce_misfit(sums, group=None):
     """In-place SUM all-reduce of a 2-element float64 tensor {sum mismatch^2, sum target^2}
     (device tensor under nccl, CPU tensor under gloo).  Returns the global objective

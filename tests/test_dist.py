@@ -25,6 +25,21 @@ def test_theta_block_partitions():
         theta_block(8, 2, 2)
 
 
+def test_theta_comb_partitions():
+    from ray_amd.dist import theta_comb
+    for ns in (1, 7, 50, 2048, 8192):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                b, e, stride, count = theta_comb(ns, r, world)
+                own = list(range(b, e, stride))
+                assert len(own) == count and stride == world
+                seen += own
+            assert sorted(seen) == list(range(ns))
+    with pytest.raises(ValueError):
+        theta_comb(8, 2, 2)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -282,6 +282,39 @@ def test_theta_block_equals_whole(ctx):
     assert empty.shape == (0, 9)
 
 
+def test_theta_comb_equals_whole(ctx, orc):
+    """RAY_OPT_SOURCE_STRIDE: rank r of n shoots the sources r, r + n, ... -- exactly those rows of the full sweep
+    (gridded medium, 3 ranks over 13 sources: combs of 5, 4, 4), and the ranks' ray-step counts are balanced where
+    contiguous blocks are not."""
+    import ray_amd
+    from ray_amd import _lib
+    from ray_amd.dist import theta_comb
+    ns, nd = 13, 64
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 75, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    full, info = ray_amd.ScatterRelation(med, None, ns, nd, 1e-2, ctx=ctx, info=True)
+    rows = np.arange(ns * nd).reshape(ns, nd)                    # row i*nd + j is source i, direction j
+    try:
+        for world in (1, 3):
+            got_rows = []
+            for r in range(world):
+                b, e, stride, count = theta_comb(ns, r, world)
+                ctx.set_option(_lib.OPT_SOURCE_STRIDE, stride)
+                part, pinfo = ray_amd.ScatterRelation(med, None, ns, nd, 1e-2, ctx=ctx, src_begin=b, src_end=e, info=True)
+                own = rows[b:e:stride].reshape(-1)
+                assert part.shape == (count * nd, 9) and own.size == count * nd
+                assert np.array_equal(part, full[own])
+                assert np.array_equal(pinfo["nsteps"], info["nsteps"][own])
+                got_rows.append(own)
+            assert np.array_equal(np.sort(np.concatenate(got_rows)), np.arange(ns * nd))
+        with pytest.raises(ray_amd.RayError):
+            ctx.set_option(_lib.OPT_SOURCE_STRIDE, 0)
+    finally:
+        ctx.set_option(_lib.OPT_SOURCE_STRIDE, 1)
+    again = ray_amd.ScatterRelation(med, None, ns, nd, 1e-2, ctx=ctx)
+    assert np.array_equal(again, full)
+
+
 # ---- gridded shoot-to-exit at scale: bit-exact against the oracle from explicit states -------------
 @pytest.mark.parametrize("N,ns,nd,dt", [(75, 100, 100, 1e-2), (512, 64, 2048, 1e-2), (45, 50, 300, 5e-2)])
 def test_grid_shoot_vs_oracle(ctx, orc, arith, N, ns, nd, dt):
