@@ -126,37 +126,13 @@ __device__ __forceinline__ void hamilton_jac(const GridDev &g, const double X[4]
     jac_from_point(g, X, q, Jm, oob);
 }
 
-// One RK4 stage of the Jacobian equation, column by column so that only four entries of V = Jm * Rin are
-// alive at a time: acc (+)= wa * V, Rout = base + c * V.  Rout may be Rin (column j of Rin is consumed
-// before it is overwritten).  Element for element the same operations as mat4_mul + the two updates.
-template <int MODE>   // 0: acc = V (stage 1); 1: acc += 2 V (stages 2, 3); 2: Rout = base + c * (acc + V) (stage 4)
-__device__ __forceinline__ void rho_stage(const double Jm[16], const double Rin[16], const double base[16],
-                                          double acc[16], double Rout[16], double c)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double t = Jm[i * 4] * Rin[j];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) t = __builtin_fma(Jm[i * 4 + k], Rin[k * 4 + j], t);
-            v[i] = t;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = i * 4 + j;
-            if (MODE == 0) { acc[e] = v[i]; Rout[e] = __builtin_fma(v[i], c, base[e]); }
-            else if (MODE == 1) { acc[e] = __builtin_fma(2.0, v[i], acc[e]); Rout[e] = __builtin_fma(v[i], c, base[e]); }
-            else Rout[e] = __builtin_fma(acc[e] + v[i], c, base[e]);
-        }
-    }
-}
-
-// The same stage with rho and the RK4 accumulator in LDS (k_frechet: two waves per SIMD need the 64 VGPRs the two
+// One RK4 stage of the Jacobian equation V = Jm * Rin (Rin = rho at stage 1, the stage argument R afterwards):
+//   acc (+)= wa * V, R = rho + c * V, and at stage 4 rho = rho + c * (acc + V)                      NonObstacle.jl:161-172
+// with rho and the RK4 accumulator in LDS (k_frechet: two waves per SIMD need the 64 VGPRs the two
 // 4x4 arrays would take).  Element pair (2m, 2m+1) of lane l sits at (m * 64 + l) * 16 from `rho_a` / `acc_a`
 // (absolute LDS byte addresses of this lane's column: + m * 1024), so every access is a conflict-free b128.
-// Two columns at a time; operation for operation what rho_stage does.  R (the stage argument) stays in registers.
+// Two columns at a time, each column's four entries of V consumed before R's column is overwritten; element for
+// element the operations of a 4x4 product and the two updates.  R (the stage argument) stays in registers.
 __device__ __forceinline__ void lds_st_d2(unsigned addr, double x, double y)
 {
     lds_d2v v;
@@ -207,19 +183,6 @@ __device__ __forceinline__ void rho_stage_lds(const double Jm[16], double R[16],
             }
         }
     }
-}
-
-__device__ __forceinline__ void mat4_mul(const double A[16], const double B[16], double C[16])
-{
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double s = A[i * 4] * B[j];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) s = __builtin_fma(A[i * 4 + k], B[k * 4 + j], s);
-            C[i * 4 + j] = s;
-        }
 }
 
 // inverse of a well-conditioned 4x4 (rho is a perturbation of a symplectic matrix, det ~ 1) by the
@@ -342,19 +305,13 @@ __device__ __forceinline__ void emit_node(const FrechetArgs &a, const double X[4
     const int cellv = q.i | (q.j << 16);
     mine[6] = make_double2(u, v);
     mine[7] = make_double2(__longlong_as_double((long long)cellv), 0.0);
-#ifndef RAY_ABL_NOTRAJ
     a.cells[(wave_base + it) * 64 + lane] = live ? cellv : -1;
-#endif
     const unsigned long long lm = __ballot(live);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                         // 512 pieces, 8 per ray
         const unsigned qq = t * 64 + lane, ray = qq >> 3, part = qq & 7;
-#ifdef RAY_ABL_NOTRAJ
-        if (((lm >> ray) & 1) && w == 1.2345e300) {
-#else
         if ((lm >> ray) & 1) {
-#endif
             const double2 piece = stage[ray * 9 + part];
             *reinterpret_cast<double2 *>(a.traj + (wave_row0 + (int64_t)ray * rows + it) * kTrajDoubles + part * 2) = piece;
         }
@@ -744,18 +701,13 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
         const uint32_t w = e < ne ? rk[e] : kSrtDead;
         double s[4] = {0, 0, 0, 0};
         int node = 0;
-#ifndef RAY_ABL_NOTHETA
         if (w != kSrtDead) theta_of_entry(recs, stride, w & 0x3FFFu, N, s, node);
-#else
-        s[0] = (double)w; node = 0;
-#endif
         if (!LDS) s_w[tid] = w;
         s_th[tid * 2] = make_double2(s[0], s[1]);
         s_th[tid * 2 + 1] = make_double2(s[2], s[3]);
         __syncthreads();
         unsigned kept = 0;                                                                   // bit i: row i keeps this head's entry
         if (w != kSrtDead && (w & 0x4000u)) {                                                // a head
-#ifndef RAY_ABL_NORUN
             for (int e2 = e + 1; e2 < ne; ++e2) {
                 const int q = e2 - t0, qc = q < 256 ? q : 255;
                 const uint32_t w2 = (LDS || q >= 256) ? rk[e2] : s_w[q];
@@ -770,7 +722,6 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
                 }
                 s[0] += th[0]; s[1] += th[1]; s[2] += th[2]; s[3] += th[3];                  // Phi += Theta (:159,175)
             }
-#endif
             const int64_t u = off + (int64_t)(w >> 15);
             double o4[4];
 #pragma unroll
@@ -778,15 +729,10 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
                 o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
                 kept |= (unsigned)((droptol < 0) || (__builtin_fabs(o4[i]) > droptol)) << i;     // droptol! (:242)
             }
-#ifdef RAY_ABL_NOSTORE
-            if (o4[0] == 1.2345e300)
-#endif
-            {
             ucols[u] = (int32_t)node;
             double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
             dst[0] = make_double2(o4[0], o4[1]);
             dst[1] = make_double2(o4[2], o4[3]);
-            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) cnt[i] += __popcll(__ballot((kept >> i) & 1u));          // the WAVE's counts, in every lane

@@ -31,8 +31,7 @@ def main():
         t_all = time.perf_counter() - t0
         cnt = ctx.counters(); ctx.enable_timing(False)
         rows, cols, nnz = F.shape[0], F.shape[1], F.nnz
-        # RAY_BENCH_NOMATVEC: ablation builds leave columns unwritten; nothing may read the matrix then
-        y = np.zeros(1) if os.environ.get("RAY_BENCH_NOMATVEC") else F.matvec(np.ones(cols))
+        y = F.matvec(np.ones(cols))
         F.close()
         if hasattr(ctx._lib, "ray_debug_fr_timeline"):        # instrumentation build (-DRAY_TIMELINE): k_frechet occupancy
             import ctypes as C
