@@ -318,8 +318,9 @@ int ray_misfit_dev(ray_ctx *ctx, const double *m_dev, const double *obs_dev, int
  * Replaces what the reference's callers get from addprocs(3) (NonObstacleDemo.jl:1, ObstacleDemo.jl:1),
  * `@sync @parallel` (NonObstacle.jl:59; Obstacle.jl:16), the per-pid remotecall_wait of ScatterForwardOperator
  * (NonObstacle.jl:236-240) and the serial misfit sum on the master (NonObstacle.jl:336,372): a single call uses
- * every worker.  A ray_group holds one ray_ctx per listed device; a call launches every member's theta-block
- * (contiguous sources, sizes differ by at most one) at once and lands each slab in the caller's column-major m;
+ * every worker.  A ray_group holds one ray_ctx per listed device; a call launches every member's share at once
+ * (member k of G: the comb of sources k, k + G, ... -- equal work per member whatever the medium's asymmetry)
+ * and lands each member's rows in the caller's column-major m;
  * nothing is exchanged between GPUs except ONE ncclAllReduce(sum, f64) of {sum mismatch^2, sum target^2} per
  * ray_group_misfit (RCCL: xGMI on the box).  `devices` may name ONE device n times (rehearsal on a one-GPU box;
  * RCCL refuses two ranks on a device): such a group folds the members' sums with a kernel on that device instead.

@@ -409,7 +409,7 @@ function Base.close(g::RayGroup)
     nothing
 end
 
-"ScatterRelation on a gridded medium over all GPUs of the group: member k shoots theta-block k"
+"ScatterRelation on a gridded medium over all GPUs of the group: member k of G shoots the sources k, k+G, ..."
 function ScatterRelation(g::RayGroup, c::Matrix{Float64}, ext::Float64, ns::Int, nd::Int, dt::Float64, dir = (0, pi))
     N = size(c, 1)
     m = SharedArray{Float64}((ns * nd, 9))

@@ -320,7 +320,7 @@ class Group:
 
     def ScatterRelation(self, med, ns, nd, dt, dir=(0.0, math.pi), *, ob=None, time_unit=TIME_SECONDS, src_begin=0,
                         src_end=None, max_steps=0, info=False, keep_on_device=False):
-        """ScatterRelation / ScatterRelationObstacle over the group: member k shoots theta-block k."""
+        """ScatterRelation / ScatterRelationObstacle over the group: member k of G shoots the comb of sources k, k + G, ..."""
         src_end = ns if src_end is None else src_end
         num = (src_end - src_begin) * nd
         m = None if keep_on_device else np.zeros((num, 9), dtype=np.float64, order="F")

@@ -4,8 +4,11 @@
 // addprocs(3) (NonObstacleDemo.jl:1, ObstacleDemo.jl:1), `@sync @parallel` (NonObstacle.jl:59, Obstacle.jl:16),
 // per-pid remotecall_wait (NonObstacle.jl:236-240), data through SharedArrays, and sums the misfit serially
 // on the master (NonObstacle.jl:336,372).  Here ONE host process drives every GPU of the node: a ray_group
-// holds one ray_ctx per device, a call launches every member's theta-block (contiguous sources, sizes differ
-// by at most one) asynchronously, each member's slab lands in the caller's column-major m, and the only
+// holds one ray_ctx per device, a call launches every member's share asynchronously -- member k of G takes the
+// COMB of sources k, k + G, ... (RAY_OPT_SOURCE_STRIDE of its context): every member sweeps the whole source
+// circle, so their ray-step counts agree whatever the medium's asymmetry, where contiguous arcs differ by 16 %
+// on the shipped medium and the call would last as long as the slowest -- each member's rows land in the
+// caller's column-major m (nd consecutive rows per source, G nd rows apart), and the only
 // exchange is ONE ncclAllReduce(sum, f64) of {sum mismatch^2, sum target^2} over RCCL (xGMI on the box).
 // A group may name one device several times (rehearsal on a one-GPU box): RCCL refuses two ranks on one
 // device, so such a group folds the members' partial sums with a one-block kernel on that device, in member
@@ -16,8 +19,11 @@
 struct GroupMember {
     ray_ctx *ctx = nullptr;
     int device = 0;
-    // slab of the last ray_group_shoot_to_exit: rows [row0, row0 + rows) of the caller's m, ld = max(rows, 1)
-    int64_t row0 = 0, rows = 0;
+    // share of the last ray_group_shoot_to_exit: `count` sources first, first + G, ... of the call, nd rows each
+    // (rows = count * nd, device ld = max(rows, 1)); in the caller's arrays source i of the share starts at row
+    // (first + i * G) * nd
+    int64_t rows = 0;
+    int first = 0, count = 0, nd = 0, G = 1;
     double *d_m = nullptr;      size_t m_cap = 0;
     int32_t *d_int = nullptr;   size_t int_cap = 0;     // status | nsteps | nreflect, rows each
     double *d_obs = nullptr;    size_t obs_cap = 0;
@@ -77,12 +83,15 @@ static void group_sync_all(ray_group *g)
             return fail(RAY_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
     } while (0)
 
-// theta-block of member k: contiguous, sizes differ by at most one (ray_amd/dist.py theta_block)
-static void member_block(int n, int k, int G, int *b, int *e)
+// One row-indexed array of the caller (w bytes per row: a column of m, status, mask, 4 doubles of mismatch ...)
+// <-> the member's packed copy of its share: `count` pieces of nd rows, G nd rows apart on the host side.
+static hipError_t comb_copy(const GroupMember &m, void *host, void *dev, size_t w, bool to_host)
 {
-    const int base = n / G, rem = n % G;
-    *b = k * base + std::min(k, rem);
-    *e = *b + base + (k < rem ? 1 : 0);
+    if (m.count == 0) return hipSuccess;
+    char *h = static_cast<char *>(host) + (size_t)m.first * (size_t)m.nd * w;
+    const size_t piece = (size_t)m.nd * w, hpitch = piece * (size_t)m.G;
+    return to_host ? hipMemcpy2DAsync(h, hpitch, dev, piece, piece, (size_t)m.count, hipMemcpyDeviceToHost, m.ctx->stream)
+                   : hipMemcpy2DAsync(dev, piece, h, hpitch, piece, (size_t)m.count, hipMemcpyHostToDevice, m.ctx->stream);
 }
 
 extern "C" {
@@ -259,10 +268,9 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_
     // 1. every member's launch, back to back (asynchronous: the GPUs run concurrently)
     for (int k = 0; k < G; ++k) {
         GroupMember &m = g->mem[(size_t)k];
-        int b, e;
-        member_block(nsrc, k, G, &b, &e);
-        m.row0 = (int64_t)b * prm->nd;
-        m.rows = (int64_t)(e - b) * prm->nd;
+        m.first = k; m.G = G; m.nd = prm->nd;
+        m.count = k < nsrc ? (nsrc - k + G - 1) / G : 0;
+        m.rows = (int64_t)m.count * prm->nd;
         if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
         const size_t rows1 = (size_t)std::max<int64_t>(m.rows, 1);
         hipError_t he = grow((void **)&m.d_m, &m.m_cap, rows1 * 9 * sizeof(double));
@@ -270,25 +278,21 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_
         if (he != hipSuccess) { group_sync_all(g); return fail(he == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, std::string("ray_group_shoot_to_exit: ") + hipGetErrorString(he)); }
         if (m.rows == 0) continue;
         ray_shoot_params sub = *prm;
-        sub.src_begin = prm->src_begin + b;
-        sub.src_end = prm->src_begin + e;
+        sub.src_begin = prm->src_begin + k;
+        m.ctx->src_stride = G;
         rc = shoot_to_exit_impl(m.ctx, gm->med[(size_t)k], ob, &sub, m.d_m, m.rows, m.d_int, m.d_int + m.rows, m.d_int + 2 * m.rows);
         if (rc) { group_sync_all(g); return rc; }
     }
-    // 2. every member's slab into the caller's column-major arrays (rows [row0, row0 + rows) of each column)
-    for (int k = 0; k < G && m_host; ++k) {
-        GroupMember &m = g->mem[(size_t)k];
-        if (m.rows == 0) continue;
-        if ((rc = use(m.ctx)) || (rc = copy_cols_d2h(m.ctx, m_host + m.row0, ld, m.d_m, m.rows, m.rows, 0, 9))) { group_sync_all(g); return rc; }
-    }
+    // 2. every member's share into the caller's column-major arrays
     for (int k = 0; k < G; ++k) {
         GroupMember &m = g->mem[(size_t)k];
-        if (m.rows == 0 || (!status && !nsteps && !nreflect)) continue;
+        if (m.rows == 0) continue;
         hipError_t he = hipSetDevice(m.device);
-        const size_t nb = sizeof(int32_t) * (size_t)m.rows;
-        if (he == hipSuccess && status) he = hipMemcpyAsync(status + m.row0, m.d_int, nb, hipMemcpyDeviceToHost, m.ctx->stream);
-        if (he == hipSuccess && nsteps) he = hipMemcpyAsync(nsteps + m.row0, m.d_int + m.rows, nb, hipMemcpyDeviceToHost, m.ctx->stream);
-        if (he == hipSuccess && nreflect) he = hipMemcpyAsync(nreflect + m.row0, m.d_int + 2 * m.rows, nb, hipMemcpyDeviceToHost, m.ctx->stream);
+        for (int c = 0; c < 9 && m_host && he == hipSuccess; ++c)
+            he = comb_copy(m, m_host + (size_t)c * (size_t)ld, m.d_m + (size_t)c * (size_t)m.rows, sizeof(double), true);
+        if (he == hipSuccess && status) he = comb_copy(m, status, m.d_int, sizeof(int32_t), true);
+        if (he == hipSuccess && nsteps) he = comb_copy(m, nsteps, m.d_int + m.rows, sizeof(int32_t), true);
+        if (he == hipSuccess && nreflect) he = comb_copy(m, nreflect, m.d_int + 2 * m.rows, sizeof(int32_t), true);
         if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_shoot_to_exit: ") + hipGetErrorString(he)); }
     }
     // 3. results valid on return
@@ -300,7 +304,7 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_
 }
 
 // the observation the misfit is taken against (NonObstacle.jl:336 `observation`), sharded like the last shoot
-// and kept resident: rows [row0, row0 + rows) of every column go to the member that owns them
+// and kept resident: the rows of every column go to the member that owns their source
 int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld)
 {
     if (!g || !obs_host) return fail(RAY_ERR_INVALID, "null group / observation");
@@ -314,7 +318,9 @@ int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num,
         hipError_t he = grow((void **)&m.d_obs, &m.obs_cap, rows1 * 9 * sizeof(double));
         if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_set_observation: ") + hipGetErrorString(he)); }
         m.obs_rows = m.rows;
-        if (m.rows && (rc = copy_cols_h2d(m.ctx, m.d_obs, m.rows, obs_host + m.row0, ld, m.rows, 4, 4))) { group_sync_all(g); return rc; }
+        for (int c = 4; c < 8 && he == hipSuccess; ++c)
+            he = comb_copy(m, const_cast<double *>(obs_host) + (size_t)c * (size_t)ld, m.d_obs + (size_t)c * (size_t)m.rows, sizeof(double), false);
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_set_observation: ") + hipGetErrorString(he)); }
     }
     for (GroupMember &m : g->mem) {
         HIPCHK(hipSetDevice(m.device));
@@ -368,8 +374,8 @@ int ray_group_misfit(ray_group *g, double out[2], uint8_t *mask, double perc_thr
     for (GroupMember &m : g->mem) {
         if (m.rows == 0) continue;
         HIPCHK(hipSetDevice(m.device));
-        if (mask) HIPCHK(hipMemcpyAsync(mask + m.row0, m.d_mask, (size_t)m.rows, hipMemcpyDeviceToHost, m.ctx->stream));
-        if (mismatch) HIPCHK(hipMemcpyAsync(mismatch + 4 * m.row0, m.d_mis, sizeof(double) * 4 * (size_t)m.rows, hipMemcpyDeviceToHost, m.ctx->stream));
+        if (mask) HIPCHK(comb_copy(m, mask, m.d_mask, 1, true));
+        if (mismatch) HIPCHK(comb_copy(m, mismatch, m.d_mis, 4 * sizeof(double), true));
     }
     for (GroupMember &m : g->mem) {
         HIPCHK(hipSetDevice(m.device));
