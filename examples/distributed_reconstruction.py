@@ -54,7 +54,7 @@ def main():
     import torch
     import torch.distributed as dist
     import ray_amd
-    from ray_amd.dist import theta_block, allreduce_loop_sums, allreduce_fidelity
+    from ray_amd.dist import theta_comb, allreduce_loop_sums, allreduce_fidelity
     from nonobstacle_reconstruction import regularization, interpolation
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,8 +74,12 @@ def main():
     sp = ray_amd.SinProd.smooth_demo()
     ns, nd, N, ext = args.ns, args.nd, args.N, 1.5
     penalty, rejection, decay, time_step = 5e-1, 1.0, 0.0, args.time_step            # NonObstacleDemo.jl:36-41
-    b, e = theta_block(ns, rank, world)
+    # this rank's rays: the comb of sources rank, rank + world, ... (equal work per rank whatever the medium; the
+    # loop only ever sums over rays, so no rank needs to know where its rows sit in a global m)
+    b, e, stride, _ = theta_comb(ns, rank, world)
+    ctx.set_option(ray_amd._lib.OPT_SOURCE_STRIDE, stride)
     m = ray_amd.ScatterRelation(sp, sp, ns, nd, args.shoot_dt, (0, np.pi), ctx=ctx, src_begin=b, src_end=e)   # this rank's rows
+    ctx.set_option(ray_amd._lib.OPT_SOURCE_STRIDE, 1)
     num = m.shape[0]
 
     p = np.zeros(N)
