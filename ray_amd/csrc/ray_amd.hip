@@ -1536,29 +1536,43 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
                                  int32_t *nsteps, ray_frechet *f)
 {
     const int max_steps = 1000000;
-    // slab sizing on the host: a ray takes at most floor(T/dt) + 2 steps (NonObstacle.jl:152-157)
+    // Slab sizing on the host: a ray takes at most floor(T/dt) + 2 steps (NonObstacle.jl:152-157).
+    // A wave steps until its longest ray is done, so the rays are regrouped before they are dealt to waves: by
+    // step-count class (1/32 of the longest), longest class first, ray order kept inside a class (a class holds
+    // runs of adjacent directions of a source: the wave stays a coherent fan).  64 consecutive rays of a 512-direction
+    // fan span chords from grazing to diameter: 83 % live lanes in ray order; the classes give >= 95 %, and the
+    // waves come out longest first, which is what fills the chip to the end of the launch.
     const int64_t nwave = (num + 63) / 64;
+    std::vector<int32_t> nst((size_t)num);
+    int cap_max = 0;
+    for (int64_t r = 0; r < num; ++r) {
+        const double T = m_host[r + 8 * ld];
+        double n = T > 0 ? std::floor(T / dt) + 2 : 0;
+        if (n > max_steps) n = max_steps;
+        nst[(size_t)r] = (int32_t)n;
+        cap_max = std::max(cap_max, (int)n);
+    }
+    const int cls_w = std::max(1, (cap_max + 31) / 32);
+    std::vector<int32_t> perm((size_t)num);
+    {   // counting sort by class, descending, stable
+        std::vector<int64_t> start(34, 0);
+        for (int64_t r = 0; r < num; ++r) ++start[(size_t)(32 - std::min(32, nst[(size_t)r] / cls_w)) + 1];
+        for (int k = 1; k < 34; ++k) start[(size_t)k] += start[(size_t)k - 1];
+        for (int64_t r = 0; r < num; ++r) {
+            const int64_t s = start[(size_t)(32 - std::min(32, nst[(size_t)r] / cls_w))]++;
+            perm[(size_t)s] = (int32_t)r;
+        }
+    }
     std::vector<int32_t> cap((size_t)nwave, 0);
     std::vector<int64_t> wave_base((size_t)nwave, 0);
     int64_t rows = 0;
-    int cap_max = 0;
     for (int64_t w = 0; w < nwave; ++w) {
-        double tmax = 0;
-        for (int64_t r = w * 64; r < num && r < (w + 1) * 64; ++r) {
-            const double T = m_host[r + 8 * ld];
-            if (T > tmax) tmax = T;
-        }
-        double n = std::floor(tmax / dt) + 2;
-        if (!(tmax > 0)) n = 0;
-        if (n > max_steps) n = max_steps;
-        cap[(size_t)w] = (int32_t)n;
-        if ((int)n > cap_max) cap_max = (int)n;
+        int n = 0;
+        for (int64_t s = w * 64; s < num && s < (w + 1) * 64; ++s) n = std::max(n, (int)nst[(size_t)perm[(size_t)s]]);
+        cap[(size_t)w] = n;
         wave_base[(size_t)w] = rows;
-        rows += frechet_rows((int)n);
+        rows += frechet_rows(n);
     }
-    std::vector<int32_t> order((size_t)nwave);
-    for (int64_t w = 0; w < nwave; ++w) order[(size_t)w] = (int32_t)w;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cap[(size_t)x] > cap[(size_t)y]; });
     if (frechet_entries(cap_max) > kMergeMaxEntries)
         return fail(RAY_ERR_UNSUPPORTED, "ScatterForwardOperator: more than 1364 steps per ray (T/dt); the per-ray merge holds 16384 stencil entries");
     const size_t slots = (size_t)rows * 64;                  // trajectory records of this call
@@ -1566,7 +1580,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     if (slots * (kTrajBytesPerRow + 12 * 36) + (size_t)num * 512 > free_b + ctx->ws_cap[0] + ctx->ws_cap[1] + ctx->ws_cap[9])
         return fail(RAY_ERR_NOMEM, "ScatterForwardOperator: the trajectory slab does not fit in device memory (sum of T/dt too large); split the rays");
-    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), dorder(ctx, 10);
+    WsBuf dm(ctx, 2), dX(ctx, 3), drho(ctx, 4), dbase(ctx, 5), dcap(ctx, 6), ducnt(ctx, 7), dperm(ctx, 10);
     RayOutBufs ob_(ctx);
     void *ptraj = nullptr, *psrt = nullptr, *pcells = nullptr;
     HIPCHK(ctx_workspace(ctx, 0, (slots ? slots : 1) * kTrajDoubles * sizeof(double), &ptraj));
@@ -1578,7 +1592,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     HIPCHK(drho.alloc(sizeof(double) * 16 * (size_t)num));
     HIPCHK(dbase.alloc(sizeof(int64_t) * (size_t)nwave));
     HIPCHK(dcap.alloc(sizeof(int32_t) * (size_t)nwave));
-    HIPCHK(dorder.alloc(sizeof(int32_t) * (size_t)nwave));
+    HIPCHK(dperm.alloc(sizeof(int32_t) * (size_t)num));
     HIPCHK(ducnt.alloc(sizeof(int32_t) * (size_t)num));
     HIPCHK(frechet_alloc(f, kFmUoff, sizeof(int64_t) * (size_t)(num + 1)));
     HIPCHK(frechet_alloc(f, kFmRowcnt, sizeof(int32_t) * 4 * (size_t)num));
@@ -1588,14 +1602,14 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
     HIPCHK(hipMemcpyAsync(dbase.p, wave_base.data(), sizeof(int64_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dcap.p, cap.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dorder.p, order.data(), sizeof(int32_t) * (size_t)nwave, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int32_t) * (size_t)num, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));           // the host vectors above are read by those copies
 
     FrechetArgs a{};
     a.med = medium_dev(med);
     a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
-    a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>(); a.wave_order = dorder.as<int32_t>();
+    a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>(); a.perm = dperm.as<int32_t>();
     a.traj = dtraj.as<double>(); a.cells = dcells.as<int32_t>();
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();
     a.status = ob_.st.as<int32_t>(); a.nsteps = ob_.ns.as<int32_t>();
@@ -1620,12 +1634,12 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
         if (sort_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL((k_merge_sort<256, uint32_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
-                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
+                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     } else {
         if (sort_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL((k_merge_sort<256, uint64_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
-                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
+                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     }
     HIPCHK(hipGetLastError());
     if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, f->uoff(), &f->U))) return rc;
@@ -1639,7 +1653,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     const char *env_grid = getenv("RAY_MERGE_GRID");
     const int64_t emit_grid = env_grid ? std::max<int64_t>(1, std::min<int64_t>(num, atoi(env_grid))) : num;
     hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes, ctx->stream,
-                       dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), ob_.ns.as<int32_t>(),
+                       dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),
                        drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
     HIPCHK(hipGetLastError());
     HIPCHK(frechet_alloc(f, kFmIndptr, sizeof(int64_t) * (size_t)(4 * num + 1)));

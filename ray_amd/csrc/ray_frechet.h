@@ -222,8 +222,7 @@ struct FrechetArgs {
     double cease_r;
     const int64_t *wave_base;   // record-row offset of every wave (a wave owns 64 x rows records from 64 * base)
     const int32_t *wave_cap;    // step capacity of every wave (rows = cap + 1 records per ray)
-    const int32_t *wave_order;  // workgroup b integrates wave wave_order[b]: longest first (a wave lasts as long as its
-                                // longest ray, 0.3 .. 2.1 ms at 512 x 512 rays, and the chip holds 2048 of 4096 at a time)
+    const int32_t *perm;        // lane l of wave w integrates ray perm[64 w + l] (rays regrouped by step count, longest first)
     double *traj;               // [wave][lane][row][16] trajectory records (kTrajDoubles)
     int32_t *cells;             // [wave][row][lane] cell of every trajectory node: i | j << 16
     double *X;                  // (num, 4) end states
@@ -338,10 +337,10 @@ __global__ __launch_bounds__(64, 2) void k_frechet(const FrechetArgs a)
         g_fr_timeline[3 * blockIdx.x + 2] = hw;
     }
 #endif
-    const int64_t wave = a.wave_order[blockIdx.x];
-    const int64_t r = wave * 64 + threadIdx.x;
-    const bool valid = r < a.num;
+    const int64_t wave = blockIdx.x;
     const unsigned lane = threadIdx.x & 63;
+    const bool valid = wave * 64 + lane < a.num;
+    const int64_t r = valid ? a.perm[wave * 64 + lane] : 0;
     if (AR == kExact) {   // node table into LDS (the look-ups read it from there; kFused takes its offsets from the cell coordinate)
         double *p_lds = reinterpret_cast<double *>(ray_smem);
         for (int k = threadIdx.x; k < a.med.g.N; k += blockDim.x) p_lds[k] = a.med.g.p[k];
@@ -518,7 +517,7 @@ __device__ __forceinline__ void sort_eight(K v[8])
 template <int BT, typename K>
 __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ cells, uint32_t *__restrict__ srt,
                                                     const int64_t *__restrict__ wave_base,
-                                                    const int32_t *__restrict__ wave_cap,
+                                                    const int32_t *__restrict__ wave_cap, const int32_t *__restrict__ perm,
                                                     const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift, int N)
 {
     typedef SortKey<K> SK;
@@ -526,7 +525,8 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     K *sk = reinterpret_cast<K *>(ray_smem);
     __shared__ int s_cnt[BT / 64];
     __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 1];
-    const int64_t ray = blockIdx.x;
+    const int slot = blockIdx.x;                        // where k_frechet integrated the ray: wave slot >> 6, lane slot & 63
+    const int64_t ray = perm[slot];                     // (workgroups in slot order: the 64 rays of a wave share their cell lines)
     const int tid = threadIdx.x;
     const int nrow = frechet_rows(nsteps[ray]);
     const int ne = nrow * kFrSlotsPerCall;
@@ -536,9 +536,9 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     }
     int n2 = 256;
     while (n2 < ne) n2 <<= 1;
-    const int64_t wb = wave_base[ray >> 6];
-    const int lane = (int)(ray & 63);
-    uint32_t *rk = srt + ray_row0(wb, wave_cap[ray >> 6], lane) * kFrSlotsPerCall;
+    const int64_t wb = wave_base[slot >> 6];
+    const int lane = slot & 63;
+    uint32_t *rk = srt + ray_row0(wb, wave_cap[slot >> 6], lane) * kFrSlotsPerCall;
     for (int r = tid; r < nrow; r += BT) s_cell[r] = cells[(wb + r) * 64 + lane];
     __syncthreads();
     const int ngroup = n2 >> 3;
@@ -754,7 +754,7 @@ constexpr int kMergeLdsRowBytes = kTrajLdsDoubles * 8 + kFrSlotsPerCall * 4;
 constexpr int kMergeLdsMaxRows = 224;           // 42 KiB; 7 record pieces and 11 sorted words per thread in flight
 __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__ srt, const double *__restrict__ traj,
                                                     const int64_t *__restrict__ wave_base, const int32_t *__restrict__ wave_cap,
-                                                    const int32_t *__restrict__ nsteps,
+                                                    const int32_t *__restrict__ perm, const int32_t *__restrict__ nsteps,
                                                     const double *__restrict__ rho, const int64_t *__restrict__ uoff,
                                                     double droptol, int N, int lds_rows, int64_t num, int32_t *__restrict__ ucols,
                                                     double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
@@ -763,7 +763,8 @@ __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__
     __shared__ double2 s_th[256 * 2];            // the tile's Theta columns
     __shared__ uint32_t s_w[256];                // the tile's sorted words (form without the LDS copy)
     const int tid = threadIdx.x;
-    for (int64_t ray = blockIdx.x; ray < num; ray += gridDim.x) {
+    for (int64_t slot = blockIdx.x; slot < num; slot += gridDim.x) {
+    const int64_t ray = perm[slot];
 #ifdef RAY_FR_PHASES
     unsigned long long t_mark = __builtin_readcyclecounter();
     if (tid == 0) atomicAdd(&g_fr_phase[0], 1ull);
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__
     if (tid < 4) s_rows[tid] = 0;
     const int nrow = frechet_rows(nsteps[ray]);
     const int ne = nrow * kFrSlotsPerCall;
-    const int64_t row0 = ray_row0(wave_base[ray >> 6], wave_cap[ray >> 6], (int)(ray & 63));
+    const int64_t row0 = ray_row0(wave_base[slot >> 6], wave_cap[slot >> 6], (int)(slot & 63));
     const uint32_t *rk = srt + row0 * kFrSlotsPerCall;
     const double *recs = traj + row0 * kTrajDoubles;
     const int64_t off = uoff[ray];

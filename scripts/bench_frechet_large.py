@@ -60,6 +60,9 @@ def main():
                           "csr_GB": nnz * 12 / 1e9, "kernel_ms": cnt["kernel_ms"], "launches": cnt["launches"],
                           "call_s": t_all, "ray_steps_per_s_call": float(info["nsteps"].sum() / t_all),
                           "bad_status": int((info["status"] & ~16).astype(bool).sum()),
+                          # k_frechet: a wave of 64 consecutive rays steps until its longest ray is done
+                          "live_lane_fraction_in_ray_order": float(info["nsteps"].sum() / (64.0 * np.add.reduceat(
+                              np.maximum.reduceat(info["nsteps"], np.arange(0, info["nsteps"].size, 64)), [0])[0])),
                           "matvec_finite": bool(np.isfinite(y).all())}), flush=True)
 
 
