@@ -1632,13 +1632,13 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8);
     if (narrow_key) {
         if (sort_lds > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<256, uint32_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<kSortThreads, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL((k_merge_sort<kSortThreads, uint32_t>), dim3((unsigned)num), dim3(kSortThreads), sort_lds, ctx->stream, dcells.as<int32_t>(),
                            dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     } else {
         if (sort_lds > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<256, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<256, uint64_t>), dim3((unsigned)num), dim3(256), sort_lds, ctx->stream, dcells.as<int32_t>(),
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<kSortThreads, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL((k_merge_sort<kSortThreads, uint64_t>), dim3((unsigned)num), dim3(kSortThreads), sort_lds, ctx->stream, dcells.as<int32_t>(),
                            dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
     }
     HIPCHK(hipGetLastError());

@@ -442,17 +442,20 @@ __global__ __launch_bounds__(64, 2) void k_frechet(const FrechetArgs a)
 }
 
 // ---- merge: distinct nodes of one ray --------------------------------------------------------------
-// One workgroup per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power of
-// two); every entry gets the rank of its node among the ray's distinct nodes and goes back to memory as
+// One workgroup (two waves) per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power
+// of two); every entry gets the rank of its node among the ray's distinct nodes and goes back to memory as
 // rank << 15 | head << 14 | emission index; ucount[ray] = number of distinct nodes.
-// The network runs in ROUNDS: a thread takes eight keys whose indices differ in three bits b..b+2, does
-// the compare-exchanges of up to three consecutive strides (2^(b+2), 2^(b+1), 2^b) in registers and puts
-// them back -- one LDS round trip per three strides, every thread of the workgroup busy in every round
-// (n2 / 8 threads' worth of work: all 256 at the usual n2 = 2048).  Keys sit padded by one per 8: the
-// eight-key groups of consecutive threads then fall on distinct banks for every b.
+// The network runs in ROUNDS: a thread takes SIXTEEN keys whose indices differ in four bits b..b+3, does the
+// compare-exchanges of up to four consecutive strides in registers and puts them back -- one LDS round trip per
+// four strides (17 rounds after the in-register start at n2 = 2048; the instruction count per key is what bounds
+// this kernel).  All-ascending form of the network: the first pass of a stage pairs i with its MIRROR image in
+// the block (i ^ (size - 1)), the rest are plain half-cleaners, so an exchange is a min / max pair without a
+// direction.  Keys sit padded by one per 16: the sixteen-key groups of consecutive threads then fall on distinct
+// banks for every b.
+constexpr int kSortThreads = 128;
 __host__ __device__ inline size_t merge_sort_lds_bytes(int n2, size_t key_bytes)
 {
-    return (size_t)(n2 + n2 / 8) * key_bytes;
+    return (size_t)(n2 + n2 / 16) * key_bytes;
 }
 
 // Sort keys.  64-bit: node << 40 | emission << 20.  32-bit (chosen by the host when the node index and
@@ -481,15 +484,15 @@ __device__ __forceinline__ void cmp_exchange(K &x, K &y)
     y = mx;
 }
 
-// half-cleaners of the strides 2^(nstr-1) .. 1 (in units of the group's own spacing) on eight keys
+// half-cleaners of the strides 2^(nstr-1) .. 1 (in units of the group's own spacing) on sixteen keys
 template <typename K>
-__device__ __forceinline__ void sort_group_strides(K v[8], int nstr)
+__device__ __forceinline__ void sort_group_strides(K v[16], int nstr)
 {
 #pragma unroll
-    for (int sb = 2; sb >= 0; --sb) {
+    for (int sb = 3; sb >= 0; --sb) {
         if (sb < nstr) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < 8; ++p) {
                 const int lo = ((p >> sb) << (sb + 1)) | (p & ((1 << sb) - 1));
                 cmp_exchange<K>(v[lo], v[lo | (1 << sb)]);
             }
@@ -497,21 +500,23 @@ __device__ __forceinline__ void sort_group_strides(K v[8], int nstr)
     }
 }
 
-// merge of two ascending runs of four (v[0..3], v[4..7]) and, before it, of runs of one and two:
-// the network in its all-ascending form -- the first pass of a stage pairs i with its MIRROR image in the
-// block (i ^ (size - 1)), the rest are plain half-cleaners -- so that no exchange needs a direction.
+// stages 2, 4, 8, 16 on sixteen consecutive keys
 template <typename K>
-__device__ __forceinline__ void sort_eight(K v[8])
+__device__ __forceinline__ void sort_sixteen(K v[16])
 {
 #pragma unroll
-    for (int p = 0; p < 8; p += 2) cmp_exchange<K>(v[p], v[p + 1]);                 // size 2
-    cmp_exchange<K>(v[0], v[3]); cmp_exchange<K>(v[1], v[2]);                        // size 4: mirror
-    cmp_exchange<K>(v[4], v[7]); cmp_exchange<K>(v[5], v[6]);
+    for (int p = 0; p < 16; p += 2) cmp_exchange<K>(v[p], v[p + 1]);                 // size 2
 #pragma unroll
-    for (int p = 0; p < 8; p += 2) cmp_exchange<K>(v[p], v[p + 1]);
+    for (int q = 0; q < 16; q += 4) { cmp_exchange<K>(v[q], v[q + 3]); cmp_exchange<K>(v[q + 1], v[q + 2]); }   // size 4: mirror
+    sort_group_strides<K>(v, 1);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) cmp_exchange<K>(v[p], v[7 - p]);                     // size 8: mirror
+    for (int q = 0; q < 16; q += 8)                                                   // size 8: mirror
+#pragma unroll
+        for (int p = 0; p < 4; ++p) cmp_exchange<K>(v[q + p], v[q + 7 - p]);
     sort_group_strides<K>(v, 2);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) cmp_exchange<K>(v[p], v[15 - p]);                     // size 16: mirror
+    sort_group_strides<K>(v, 3);
 }
 
 template <int BT, typename K>
@@ -521,13 +526,13 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
                                                     const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift, int N)
 {
     typedef SortKey<K> SK;
-    auto spad = [](int i) { return i + (i >> 3); };
+    auto spad = [](int i) { return i + (i >> 4); };
     K *sk = reinterpret_cast<K *>(ray_smem);
     __shared__ int s_cnt[BT / 64];
-    __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 1];
-    const int slot = blockIdx.x;                        // where k_frechet integrated the ray: wave slot >> 6, lane slot & 63
-    const int64_t ray = perm[slot];                     // (workgroups in slot order: the 64 rays of a wave share their cell lines)
+    __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 3];
     const int tid = threadIdx.x;
+    const int64_t slot = blockIdx.x;                    // where k_frechet integrated the ray: wave slot >> 6, lane slot & 63
+    const int64_t ray = perm[slot];                     // (workgroups in slot order: the 64 rays of a wave share their cell lines)
     const int nrow = frechet_rows(nsteps[ray]);
     const int ne = nrow * kFrSlotsPerCall;
     if (ne == 0) {
@@ -537,75 +542,76 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     int n2 = 256;
     while (n2 < ne) n2 <<= 1;
     const int64_t wb = wave_base[slot >> 6];
-    const int lane = slot & 63;
+    const int lane = (int)(slot & 63);
     uint32_t *rk = srt + ray_row0(wb, wave_cap[slot >> 6], lane) * kFrSlotsPerCall;
-    for (int r = tid; r < nrow; r += BT) s_cell[r] = cells[(wb + r) * 64 + lane];
+    for (int r = tid; r < nrow + 2; r += BT) s_cell[r] = r < nrow ? cells[(wb + r) * 64 + lane] : 0;
     __syncthreads();
-    const int ngroup = n2 >> 3;
-    for (int t = tid; t < ngroup; t += BT) {                       // keys of eight consecutive entries; stages 2, 4, 8
-        K v[8];
-        // eight consecutive entries lie in at most two records: slot k0 + j of record r0, or slot k0 + j - 12 of r0 + 1
-        const int e0 = t * 8;
-        const int r0 = (int)(((unsigned)e0 * 43691u) >> 19), k0 = e0 - r0 * kFrSlotsPerCall;        // e0 / 12 for e0 < 2^16
-        const int cva = e0 < ne ? s_cell[r0] : 0, cvb = r0 + 1 < nrow ? s_cell[r0 + 1] : 0;
-        const int ia = cva & 0xffff, ja = cva >> 16, ib = cvb & 0xffff, jb = cvb >> 16;
+    const int ngroup = n2 >> 4;
+    for (int t = tid; t < ngroup; t += BT) {                       // keys of sixteen consecutive entries; stages 2 .. 16
+        K v[16];
+        // sixteen consecutive entries lie in at most three records: slot k0 + j of record r0, or the next ones'
+        const int e0 = t * 16;
+        const int r0 = e0 < ne ? (int)(((unsigned)e0 * 43691u) >> 19) : 0, k0 = e0 - r0 * kFrSlotsPerCall;   // e0 / 12 for e0 < 2^16
+        const int cva = s_cell[r0], cvb = s_cell[r0 + 1], cvc = s_cell[r0 + 2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool nxt = k0 + j >= kFrSlotsPerCall;
-            const int k = nxt ? k0 + j - kFrSlotsPerCall : k0 + j;
-            const int ni = (nxt ? ib : ia) + stencil_di(k), nj = (nxt ? jb : ja) + stencil_dj(k);
+        for (int j = 0; j < 16; ++j) {
+            const int kk = k0 + j;
+            const int ro = kk >= 2 * kFrSlotsPerCall ? 2 : kk >= kFrSlotsPerCall ? 1 : 0;
+            const int k = kk - ro * kFrSlotsPerCall;
+            const int cv = ro == 2 ? cvc : ro == 1 ? cvb : cva;
+            const int ni = (cv & 0xffff) + stencil_di(k), nj = (cv >> 16) + stencil_dj(k);
             const bool ok = e0 + j < ne && (unsigned)ni < (unsigned)N && (unsigned)nj < (unsigned)N;
             const K key = SK::pack((int64_t)ni + (int64_t)nj * N, e0 + j, eshift);
             v[j] = ok ? key : SK::dead();
         }
-        sort_eight<K>(v);
+        sort_sixteen<K>(v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sk[t * 9 + j] = v[j];
+        for (int j = 0; j < 16; ++j) sk[t * 17 + j] = v[j];
     }
     __syncthreads();
-    for (int top0 = 3; (1 << top0) < n2; ++top0) {                 // stage size = 2^(top0 + 1)
-        {   // first round: the mirror pass and the strides 2^(top0-1), 2^(top0-2); a thread's four upper keys sit at
-            // the complemented low bits, which puts every mirror pair (j, 7 - j) into one thread
-            const int b = top0 - 2, lm = (1 << b) - 1;
-            unsigned d[8];                                          // uniform: spad(j << b) in bytes
+    for (int top0 = 4; (1 << top0) < n2; ++top0) {                 // stage size = 2^(top0 + 1)
+        {   // first round: the mirror pass and the strides 2^(top0-1) .. 2^(top0-3); a thread's eight upper keys sit at
+            // the complemented low bits, which puts every mirror pair (j, 15 - j) into one thread
+            const int b = top0 - 3, lm = (1 << b) - 1;
+            unsigned d[16];                                         // uniform: spad(j << b) in bytes
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
+            for (int j = 0; j < 16; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
             for (int t = tid; t < ngroup; t += BT) {
-                const int hi = (t >> b) << (b + 3), lo = t & lm;
+                const int hi = (t >> b) << (b + 4), lo = t & lm;
                 const unsigned a_lo = (unsigned)sizeof(K) * (unsigned)spad(hi | lo), a_hi = (unsigned)sizeof(K) * (unsigned)spad(hi | (lo ^ lm));
                 char *base = reinterpret_cast<char *>(sk);
-                K v[8];
+                K v[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<K *>(base + (j < 4 ? a_lo : a_hi) + d[j]);
+                for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<K *>(base + (j < 8 ? a_lo : a_hi) + d[j]);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) cmp_exchange<K>(v[p], v[7 - p]);
-                sort_group_strides<K>(v, 2);
+                for (int p = 0; p < 8; ++p) cmp_exchange<K>(v[p], v[15 - p]);
+                sort_group_strides<K>(v, 3);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<K *>(base + (j < 4 ? a_lo : a_hi) + d[j]) = v[j];
+                for (int j = 0; j < 16; ++j) *reinterpret_cast<K *>(base + (j < 8 ? a_lo : a_hi) + d[j]) = v[j];
             }
             __syncthreads();
         }
-        for (int top = top0 - 3; top >= 0;) {                      // half-cleaners 2^top .. 2^b in one round
-            const int b = top >= 2 ? top - 2 : 0;
-            unsigned d[8];
+        for (int top = top0 - 4; top >= 0;) {                      // half-cleaners 2^top .. 2^b in one round
+            const int b = top >= 3 ? top - 3 : 0;
+            unsigned d[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
+            for (int j = 0; j < 16; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
             for (int t = tid; t < ngroup; t += BT) {
-                const unsigned a0 = (unsigned)sizeof(K) * (unsigned)spad(((t >> b) << (b + 3)) | (t & ((1 << b) - 1)));
+                const unsigned a0 = (unsigned)sizeof(K) * (unsigned)spad(((t >> b) << (b + 4)) | (t & ((1 << b) - 1)));
                 char *base = reinterpret_cast<char *>(sk);
-                K v[8];
+                K v[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<K *>(base + a0 + d[j]);
+                for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<K *>(base + a0 + d[j]);
                 sort_group_strides<K>(v, top - b + 1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<K *>(base + a0 + d[j]) = v[j];
+                for (int j = 0; j < 16; ++j) *reinterpret_cast<K *>(base + a0 + d[j]) = v[j];
             }
             __syncthreads();
             top = b - 1;
         }
     }
     // rank of each entry's node: heads counted per contiguous chunk of n2 / BT keys, scanned over the BT threads
-    // (inclusive scan inside the wave by shuffles, the four wave totals through LDS)
+    // (inclusive scan inside the wave by shuffles, the wave totals through LDS)
     const int cs = n2 / BT, e0 = tid * cs;
     const K before = e0 > 0 ? sk[spad(e0 - 1)] : SK::dead();       // dead sorts last: never equal to a live key's node
     int heads = 0;

@@ -26,6 +26,26 @@ def _data(orc, N, ns, nd, arith, bump=0.0):
     return c, tab, np.asfortranarray(m)
 
 
+def test_forward_operator_long_rays(ctx, orc):
+    """rays of ~500-1200 steps (dt = 2e-3): 16384-key sorts that loop over key groups, records read in place by the
+    merge (more than 224 rows), mixed with short and zero-time rays in one call; and the step limit."""
+    import ray_amd
+    c, tab, m = _data(orc, 31, 3, 8, 1)
+    m[5, 8] = 0.0                                                  # a ray that takes no step
+    m[7, 8] *= 0.05                                                # and a short one
+    dt = 2e-3
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+    assert 700 < nso.max() <= 1364 and nso.min() == 0
+    M, s, info = ray_amd.ScatterForwardOperator(c, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(info["nsteps"], nso) and np.array_equal(info["status"], sto)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(info["rho"] - rho_o)) <= MTOL * np.max(np.abs(rho_o))
+    assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+    assert M[4 * 5:4 * 5 + 4].nnz == 0
+    with pytest.raises(ray_amd.RayError):                          # more than 1364 steps: the per-ray merge is sized for 16384 entries
+        ray_amd.ScatterForwardOperator(c, m, 1.5, 5e-4, ctx=ctx)
+
+
 @pytest.mark.parametrize("N,ns,nd,dt", [(31, 4, 16, 5e-2), (61, 5, 13, 5e-2), (75, 3, 70, 2e-2)])
 def test_forward_operator_matches_oracle(ctx, orc, arith, N, ns, nd, dt):
     import ray_amd
