@@ -2096,9 +2096,9 @@ int ray_debug_stats(unsigned long long out[12])
 
 #ifdef RAY_FR_PHASES
 // instrumentation build only: summed phase cycles of k_merge_emit since the last call
-int ray_debug_fr_phases(unsigned long long out[8])
+int ray_debug_fr_phases(unsigned long long out[16])
 {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_phase), sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_fr_phase), z, sizeof(z)) != hipSuccess) return RAY_ERR_HIP;
     return RAY_OK;

@@ -441,6 +441,15 @@ __global__ __launch_bounds__(64, 2) void k_frechet(const FrechetArgs a)
 #endif
 }
 
+#ifdef RAY_FR_PHASES
+// instrumentation build: summed cycles per phase, k_merge_emit [0] workgroups, [1..4] meta / copy / tiles / tail;
+// k_merge_sort [8] workgroups, [9..12] meta + cells / keys + first 16 / rounds / ranking
+__device__ unsigned long long g_fr_phase[16];
+#define RAY_FR_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_fr_phase[k], t_ - t_mark); t_mark = t_; } } while (0)
+#else
+#define RAY_FR_MARK(k) do { } while (0)
+#endif
+
 // ---- merge: distinct nodes of one ray --------------------------------------------------------------
 // One workgroup (two waves) per ray.  Keys (node, emission index) are sorted in LDS (bitonic, n2 = next power
 // of two); every entry gets the rank of its node among the ray's distinct nodes and goes back to memory as
@@ -531,6 +540,10 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     __shared__ int s_cnt[BT / 64];
     __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 3];
     const int tid = threadIdx.x;
+#ifdef RAY_FR_PHASES
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    if (tid == 0) atomicAdd(&g_fr_phase[8], 1ull);
+#endif
     const int64_t slot = blockIdx.x;                    // where k_frechet integrated the ray: wave slot >> 6, lane slot & 63
     const int64_t ray = perm[slot];                     // (workgroups in slot order: the 64 rays of a wave share their cell lines)
     const int nrow = frechet_rows(nsteps[ray]);
@@ -541,11 +554,13 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     }
     int n2 = 256;
     while (n2 < ne) n2 <<= 1;
+    RAY_FR_MARK(13);
     const int64_t wb = wave_base[slot >> 6];
     const int lane = (int)(slot & 63);
     uint32_t *rk = srt + ray_row0(wb, wave_cap[slot >> 6], lane) * kFrSlotsPerCall;
     for (int r = tid; r < nrow + 2; r += BT) s_cell[r] = r < nrow ? cells[(wb + r) * 64 + lane] : 0;
     __syncthreads();
+    RAY_FR_MARK(9);
     const int ngroup = n2 >> 4;
     for (int t = tid; t < ngroup; t += BT) {                       // keys of sixteen consecutive entries; stages 2 .. 16
         K v[16];
@@ -569,6 +584,7 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
         for (int j = 0; j < 16; ++j) sk[t * 17 + j] = v[j];
     }
     __syncthreads();
+    RAY_FR_MARK(10);
     for (int top0 = 4; (1 << top0) < n2; ++top0) {                 // stage size = 2^(top0 + 1)
         {   // first round: the mirror pass and the strides 2^(top0-1) .. 2^(top0-3); a thread's eight upper keys sit at
             // the complemented low bits, which puts every mirror pair (j, 15 - j) into one thread
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
             top = b - 1;
         }
     }
+    RAY_FR_MARK(11);
     // rank of each entry's node: heads counted per contiguous chunk of n2 / BT keys, scanned over the BT threads
     // (inclusive scan inside the wave by shuffles, the wave totals through LDS)
     const int cs = n2 / BT, e0 = tid * cs;
@@ -641,18 +658,29 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
     }
     int rank = wave_before + incl - heads - 1;      // rank of the last head before this chunk
     if (tid == 0) ucount[ray] = total;
+    // The words replace the keys in LDS (every thread has read the key before its chunk by now: barrier above), then
+    // go to memory with consecutive lanes on consecutive words: a thread storing its own chunk word by word touches
+    // 64 different lines per instruction, and those partial-line stores were 40 % of this kernel's time.
+    uint32_t *sw = reinterpret_cast<uint32_t *>(ray_smem);
+    constexpr int kw = (int)(sizeof(K) / 4);          // a key's slot holds its word in the first four bytes
     {
         uint64_t pn = e0 > 0 && before != SK::dead() ? SK::node(before, eshift) : ~0ull;
         for (int e = e0; e < e0 + cs; ++e) {
             const K k = sk[spad(e)];
-            if (k == SK::dead()) { if (e < ne) rk[e] = kSrtDead; continue; }
-            const uint64_t nd = SK::node(k, eshift);
-            const bool head = nd != pn;
-            pn = nd;
-            rank += head;
-            rk[e] = (uint32_t)rank << 15 | (uint32_t)head << 14 | SK::emission(k, eshift);
+            uint32_t w = kSrtDead;
+            if (k != SK::dead()) {
+                const uint64_t nd = SK::node(k, eshift);
+                const bool head = nd != pn;
+                pn = nd;
+                rank += head;
+                w = (uint32_t)rank << 15 | (uint32_t)head << 14 | SK::emission(k, eshift);
+            }
+            sw[spad(e) * kw] = w;
         }
     }
+    __syncthreads();
+    for (int e = tid; e < ne; e += BT) rk[e] = sw[spad(e) * kw];
+    RAY_FR_MARK(12);
 }
 
 // Theta column of emission e = 12 row + k from the ray's trajectory records (see kTrajDoubles)
@@ -750,12 +778,6 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
 // (ucols, uvals[4]) at uoff[ray] and the per-matrix-row entry counts that survive droptol.
 // Rays of at most `lds_rows` records go through the LDS form of emit_tiles (dynamic shared memory:
 // lds_rows * kMergeLdsRowBytes), longer ones read records and sorted words in place.
-#ifdef RAY_FR_PHASES
-__device__ unsigned long long g_fr_phase[8];     // k_merge_emit: [0] workgroups, [1..4] summed cycles of meta / copy / tiles / tail
-#define RAY_FR_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_fr_phase[k], t_ - t_mark); t_mark = t_; } } while (0)
-#else
-#define RAY_FR_MARK(k) do { } while (0)
-#endif
 constexpr int kMergeLdsRowBytes = kTrajLdsDoubles * 8 + kFrSlotsPerCall * 4;
 constexpr int kMergeLdsMaxRows = 224;           // 42 KiB; 7 record pieces and 11 sorted words per thread in flight
 __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__ srt, const double *__restrict__ traj,

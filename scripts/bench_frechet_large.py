@@ -50,11 +50,14 @@ def main():
                                                       "start_ticks_percentiles_0_50_100": [int(np.percentile(tl[:, 0] - t0, q)) for q in (0, 50, 100)]}}), flush=True)
         if hasattr(ctx._lib, "ray_debug_fr_phases"):          # instrumentation build (-DRAY_FR_PHASES)
             import ctypes as C
-            ph = (C.c_ulonglong * 8)()
+            ph = (C.c_ulonglong * 16)()
             ctx._lib.ray_debug_fr_phases(ph)
             n = max(ph[0], 1)
             print(json.dumps({"merge_emit_phases_cycles_per_workgroup": {"workgroups": ph[0], "meta": ph[1] / n, "copy": ph[2] / n,
-                                                                          "tiles": ph[3] / n, "tail": ph[4] / n}}), flush=True)
+                                                                          "tiles": ph[3] / n, "tail": ph[4] / n},
+                              "merge_sort_phases_cycles_per_workgroup": {"workgroups": ph[8], "perm_nsteps": ph[13] / max(ph[8], 1), "base_cells": ph[9] / max(ph[8], 1),
+                                                                         "keys_first16": ph[10] / max(ph[8], 1), "rounds": ph[11] / max(ph[8], 1),
+                                                                         "ranking": ph[12] / max(ph[8], 1)}}), flush=True)
         print(json.dumps({"workload": f"ScatterForwardOperator {ns}x{nd} rays, N={N}, dt={dt}", "call": rep,
                           "rays": int(m.shape[0]), "ray_steps": int(info["nsteps"].sum()), "nnz": int(nnz),
                           "csr_GB": nnz * 12 / 1e9, "kernel_ms": cnt["kernel_ms"], "launches": cnt["launches"],
