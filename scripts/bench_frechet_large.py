@@ -31,7 +31,8 @@ def main():
         t_all = time.perf_counter() - t0
         cnt = ctx.counters(); ctx.enable_timing(False)
         rows, cols, nnz = F.shape[0], F.shape[1], F.nnz
-        y = F.matvec(np.ones(cols))
+        # RAY_BENCH_NOMATVEC: ablation builds may leave the matrix unwritten; nothing may read it then
+        y = np.zeros(1) if os.environ.get("RAY_BENCH_NOMATVEC") else F.matvec(np.ones(cols))
         F.close()
         if hasattr(ctx._lib, "ray_debug_fr_timeline"):        # instrumentation build (-DRAY_TIMELINE): k_frechet occupancy
             import ctypes as C
