@@ -102,7 +102,7 @@ def main():
 
     for it in range(args.iters):
         t0 = time.perf_counter()
-        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx)       # NonObstacle.jl:333
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx, want_rho=False)       # NonObstacle.jl:333
         mismatch = (m[:, 4:8] - X).reshape(-1)                                                 # :336
         dofs = F.dofs(fidelity)                                                                # :340-342
         mask = (dofs <= args.rank_thres).astype(np.uint8)                                      # :345-348
@@ -175,7 +175,7 @@ def loop_matrix_free(args, ctx, sp, m, c, c0, R, Idx, Ldx, N, ext, h, penalty, r
     cv = c.reshape(-1, order="F")[Ldx]
     for it in range(args.iters):
         t0 = time.perf_counter()
-        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx)        # NonObstacle.jl:333
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx, want_rho=False)        # NonObstacle.jl:333
         mism_d = torch.from_numpy((m[:, 4:8] - X).reshape(-1)).to(dev)                         # :336
         rdev.frechet_dofs_dev(F, fid_d.data_ptr(), dofs_d.data_ptr())                          # :340-342
         mask_d = (dofs_d[:num] <= args.rank_thres).to(torch.uint8)                             # :345-348

@@ -60,7 +60,7 @@ def reconstruct(m, N, ext, penalty, rejection, decay, rank_thres, wave_speed, ti
     hist = []
     for it in range(iters):
         t0 = time.perf_counter()
-        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx)   # :333
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx, want_rho=False)   # :333
         t_forward = time.perf_counter() - t0
         mismatch = (m[:, 4:8] - X).reshape(-1)                                       # :336
         t0 = time.perf_counter()

@@ -44,7 +44,7 @@ def reconstruct(ns, nd, N, iters, ctx, log=print):
     med = ray_amd.GridMedium(c0, ext, ctx)
     hist = []
     for it in range(iters):
-        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx)      # :199
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, ext, time_step, ctx=ctx, want_rho=False)      # :199
         obs = np.asfortranarray(m.copy())
         obs[:, 4:8] = X
         mf = ray_amd.misfit(m, obs, 0.2, ctx=ctx)                                    # :202,217-226 on the GPU

@@ -607,9 +607,10 @@ class FrechetMatrix:
             pass
 
 
-def forward_operator_dev(c, m, ext, dt, *, ctx=None, droptol=1e-12):
+def forward_operator_dev(c, m, ext, dt, *, ctx=None, droptol=1e-12, want_rho=True):
     """The complete ChunkProcessing! pass (NonObstacle.jl:146-185) on the GPU: returns
-    (FrechetMatrix [device CSR], X (num, 4), rho (num, 4, 4), info)."""
+    (FrechetMatrix [device block rows], X (num, 4), rho (num, 4, 4), info).  want_rho=False skips the download of
+    the Jacobians (128 B per ray; the reconstruction loop never looks at them): rho is None then."""
     ctx = ctx or default_context()
     if isinstance(c, SinProd):
         raise RayError("ScatterForwardOperator is defined on gridded media only (NonObstacle.jl:189)")
@@ -617,13 +618,13 @@ def forward_operator_dev(c, m, ext, dt, *, ctx=None, droptol=1e-12):
     m = np.asfortranarray(m, dtype=np.float64)
     num = m.shape[0]
     X = np.zeros((num, 4), dtype=np.float64, order="F")
-    rho = np.zeros((num, 4, 4), dtype=np.float64)
+    rho = np.zeros((num, 4, 4), dtype=np.float64) if want_rho else None
     st = np.zeros(num, dtype=np.int32)
     nst = np.zeros(num, dtype=np.int32)
     h = C.c_void_p()
     _lib.check(ctx._lib.ray_forward_operator(ctx.handle, med.handle, _ptr(m), num, max(num, 1), float(dt),
                                              -1.0 if droptol is None else float(droptol),
-                                             _ptr(X), max(num, 1), _ptr(rho), _ptr(st), _ptr(nst),
+                                             _ptr(X), max(num, 1), _ptr(rho) if want_rho else None, _ptr(st), _ptr(nst),
                                              C.byref(h)))
     return FrechetMatrix(ctx, h), X, rho, {"status": st, "nsteps": nst}
 
