@@ -43,6 +43,7 @@ const TIME_SECONDS = Cint(0)
 const TIME_STEPS = Cint(1)
 const TRACE_SHORTEN_CEASE = Cint(0)
 const TRACE_OVERSHOOT = Cint(1)
+const RAY_OPT_FAN_DIRECTIONS = Cint(3)
 
 # ---- descriptors ------------------------------------------------------------------------------------
 "c = 1 + A sin(wx x) sin(wy y); âˆ‡c = [gx cos(wx x) sin(wy y), gy sin(wx x) cos(wy y)]"
@@ -174,8 +175,11 @@ function ScatterRelationObstacle(c::Analytic, âˆ‡c, ob::Union{Circle,Trefoil}, â
     m
 end
 
-function trace(c::Matrix{Float64}, m::AbstractMatrix{Float64}, ext::Float64, dt::Float64, mode::Cint)
+# nd > 0: the rows of m are fans of nd directions per source (ScatterRelation's layout); a layout hint for the
+# kernel (RAY_OPT_FAN_DIRECTIONS), the results do not depend on it.
+function trace(c::Matrix{Float64}, m::AbstractMatrix{Float64}, ext::Float64, dt::Float64, mode::Cint; nd::Int = 0)
     num = size(m, 1)
+    check(ccall((:ray_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), context(), RAY_OPT_FAN_DIRECTIONS, nd))
     mm = Matrix{Float64}(m)                       # dense column-major copy (m may be a view)
     X = Matrix{Float64}(undef, num, 4)
     with_medium(c, ext) do med
@@ -220,8 +224,8 @@ function ScatterForwardOperator(c::Matrix{Float64}, m, ext::Float64, dt::Float64
 end
 
 # ---- Obstacle.jl:275 --------------------------------------------------------------------------------------
-function NonReflectionTrace(c::Matrix{Float64}, m, ext::Float64, dt::Float64)
-    m[:, 5:8] = trace(c, m, ext, dt, TRACE_OVERSHOOT)
+function NonReflectionTrace(c::Matrix{Float64}, m, ext::Float64, dt::Float64; nd::Int = 0)
+    m[:, 5:8] = trace(c, m, ext, dt, TRACE_OVERSHOOT; nd = nd)
     m
 end
 

@@ -491,7 +491,10 @@ def NonReflectionPlot(c, m, ext, dt, *, ctx=None, max_pts=4096, info=False):
     return paths
 
 
-def _trace(c, m, ext, dt, mode, ctx, info):
+def _trace(c, m, ext, dt, mode, ctx, info, nd=0):
+    """`nd` > 0 tells the library the rays are fans (row = source * nd + direction), so that the trace
+    kernel packs neighbouring directions into one wave as the shooter does (RAY_OPT_FAN_DIRECTIONS);
+    the results do not depend on it."""
     ctx = ctx or default_context()
     if isinstance(c, SinProd):
         raise RayError("fixed-time tracing is defined on gridded media only (NonObstacle.jl:189, "
@@ -502,9 +505,14 @@ def _trace(c, m, ext, dt, mode, ctx, info):
     X = np.zeros((num, 4), dtype=np.float64, order="F")
     st = np.zeros(num, dtype=np.int32)
     nst = np.zeros(num, dtype=np.int32)
-    _lib.check(ctx._lib.ray_trace_fixed_time(ctx.handle, med.handle, _ptr(m), num, max(num, 1),
-                                             float(dt), mode, _ptr(X), max(num, 1), _ptr(st),
-                                             _ptr(nst)))
+    ctx.set_option(_lib.OPT_FAN_DIRECTIONS, int(nd))
+    try:
+        _lib.check(ctx._lib.ray_trace_fixed_time(ctx.handle, med.handle, _ptr(m), num, max(num, 1),
+                                                 float(dt), mode, _ptr(X), max(num, 1), _ptr(st),
+                                                 _ptr(nst)))
+    finally:
+        if nd:
+            ctx.set_option(_lib.OPT_FAN_DIRECTIONS, 0)
     return X, {"status": st, "nsteps": nst}
 
 
@@ -646,9 +654,10 @@ def ScatterForwardOperator(c, m, ext, dt, *, ctx=None, info=False, droptol=1e-12
     return (M, s, inf) if info else (M, s)
 
 
-def NonReflectionTrace(c, m, ext, dt, *, ctx=None, info=False):
-    """Obstacle.jl:275-329: m with columns 5..8 overwritten by the fixed-time end states."""
-    X, inf = _trace(c, m, ext, dt, TRACE_OVERSHOOT, ctx, info)
+def NonReflectionTrace(c, m, ext, dt, *, ctx=None, info=False, nd=0):
+    """Obstacle.jl:275-329: m with columns 5..8 overwritten by the fixed-time end states.  `nd`: the fan
+    width of m (rows = source * nd + direction) as a layout hint for the kernel, 0 = none."""
+    X, inf = _trace(c, m, ext, dt, TRACE_OVERSHOOT, ctx, info, nd)
     out = np.array(m, dtype=np.float64, order="F", copy=True)
     out[:, 4:8] = X
     return (out, inf) if info else out

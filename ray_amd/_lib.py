@@ -15,6 +15,7 @@ ARITH_EXACT, ARITH_FUSED = 0, 1
 STREAM_OWN, STREAM_BORROWED = 0, 1
 OPT_SKIP_INIT_COLUMNS = 1
 OPT_SOURCE_STRIDE = 2
+OPT_FAN_DIRECTIONS = 3
 
 
 class RayError(RuntimeError):

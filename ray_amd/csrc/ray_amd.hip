@@ -377,6 +377,11 @@ struct TraceArgs {
     double *path;         // PATH variant: [ray][point][x,y] polylines (NonReflectionPlot's `res`), else null
     int32_t *npts;
     int max_pts;
+    // RAY_OPT_FAN_DIRECTIONS: the rows are nsrc fans of nd consecutive directions (row i*nd + j, as ScatterRelation
+    // lays m out).  nd > 0 selects k_shoot's work mapping: a wave is a patch of 2^(6-dshift) adjacent sources x
+    // 2^dshift directions, a workgroup the same direction chunk of adjacent source patches, chunks dispatched from the
+    // middle of the fan outwards (longest chords first), the XCDs' source arcs rotating from chunk to chunk.
+    int nd, nsrc, ngroup, dshift;
 };
 
 // a8 (mode OVERSHOOT, Obstacle.jl:306-326) and a9 X-trajectory (mode SHORTEN_CEASE,
@@ -387,8 +392,22 @@ struct TraceArgs {
 template <int AR, int PATH = 0>
 __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = r < a.num;
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = r < a.num;
+    if (a.nd > 0) {                                          // fan-aware mapping, as in k_shoot
+        const int dmask = (1 << a.dshift) - 1;
+        const int nchunk = (a.nd + dmask) >> a.dshift;
+        const int rank = (int)(blockIdx.x / (unsigned)a.ngroup);
+        int gi = (int)(blockIdx.x - (unsigned)rank * (unsigned)a.ngroup);
+        if ((a.ngroup & 7) == 0) gi = (((gi & 7) + RAY_ARC_ROT(rank)) & 7) * (a.ngroup >> 3) + (gi >> 3);
+        const int mid = nchunk >> 1, hh = (rank + 1) >> 1;
+        const int chunk = (rank & 1) ? mid - hh : mid + hh;
+        const int lane = (int)(threadIdx.x & 63);
+        const int64_t il = (((int64_t)gi * (blockDim.x >> 6) + (threadIdx.x >> 6)) << (6 - a.dshift)) + (lane >> a.dshift);
+        const int j = (chunk << a.dshift) + (lane & dmask);
+        valid = il < a.nsrc && j < a.nd;
+        r = valid ? il * a.nd + j : 0;
+    }
     const GridAcc acc = grid_acc_setup<AR == kExact>(a.med.g);
     double X[4] = {0, 0, 1, 0};
     double T = 0;
@@ -628,6 +647,7 @@ struct ray_ctx {
     size_t ws_cap[kWs] = {};
     bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
     int src_stride = 1;                        // RAY_OPT_SOURCE_STRIDE
+    int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
     static constexpr int kPool = 7;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows)
@@ -1366,9 +1386,21 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     a.max_steps = 10000000;
     a.X = X_dev; a.ldx = ldx; a.status = status_dev; a.nsteps = nsteps_dev;
     a.step_counter = ctx->d_steps;
+    unsigned nblk = (unsigned)((num + block_threads() - 1) / block_threads());
+    if (ctx->fan_nd > 0 && num % ctx->fan_nd == 0) {        // the rows are fans of fan_nd directions: k_shoot's mapping
+        const int wpb = block_threads() / 64;
+        a.nd = ctx->fan_nd;
+        a.nsrc = (int)(num / ctx->fan_nd);
+        int dshift = 5;
+        while (dshift > 2 && (1 << (dshift - 1)) >= a.nd) --dshift;
+        a.dshift = dshift;
+        const int spb = wpb << (6 - dshift), dpw = 1 << dshift;
+        a.ngroup = (a.nsrc + spb - 1) / spb;
+        nblk = (unsigned)(((a.nd + dpw - 1) / dpw) * a.ngroup);
+    }
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    const dim3 tgrid((unsigned)((num + block_threads() - 1) / block_threads())), tblock(block_threads());
+    const dim3 tgrid(nblk), tblock(block_threads());
     if (path_dev) {
         a.path = path_dev; a.npts = npts_dev; a.max_pts = max_pts;
         if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 1>), tgrid, tblock, nodes_lds_bytes(med, true), ctx->stream, a);
@@ -2172,6 +2204,11 @@ int ray_ctx_set_option(ray_ctx *ctx, int option, int value)
 {
     if (!ctx) return fail(RAY_ERR_INVALID, "null context");
     if (option == RAY_OPT_SKIP_INIT_COLUMNS) { ctx->skip_init_cols = value != 0; return RAY_OK; }
+    if (option == RAY_OPT_FAN_DIRECTIONS) {
+        if (value < 0) return fail(RAY_ERR_INVALID, "fan directions must be >= 0");
+        ctx->fan_nd = value;
+        return RAY_OK;
+    }
     if (option == RAY_OPT_SOURCE_STRIDE) {
         if (value < 1) return fail(RAY_ERR_INVALID, "source stride must be >= 1");
         ctx->src_stride = value;

@@ -88,9 +88,12 @@ def main():
     ctx.set_arith(ray_amd.ARITH_FUSED)
     shoot(gsmooth, None, 0)()
     ctx.synchronize()
-    for mode, nm in ((0, "trace a9 shorten+cease dt=5e-2"), (1, "trace a8 overshoot dt=5e-2")):
-        run(nm, lambda: rdev.trace_fixed_time_dev(ctx, gsmooth, m.data_ptr(), num, num, 5e-2, mode, X.data_ptr(), num,
-                                                  status_ptr=st.data_ptr(), nsteps_ptr=nst.data_ptr()))
+    for tdt, fan in ((5e-2, 0), (1e-2, 0), (5e-2, nd), (1e-2, nd)):   # the reconstruction's step and the shooting step; rows as given / fan hint
+      ctx.set_option(ray_amd._lib.OPT_FAN_DIRECTIONS, fan)
+      for _ in (0,):
+        for mode, nm in ((0, f"trace a9 shorten+cease dt={tdt:g} fan={fan}"), (1, f"trace a8 overshoot dt={tdt:g} fan={fan}")):
+            run(nm, lambda: rdev.trace_fixed_time_dev(ctx, gsmooth, m.data_ptr(), num, num, tdt, mode, X.data_ptr(), num,
+                                                      status_ptr=st.data_ptr(), nsteps_ptr=nst.data_ptr()))
 
 
 if __name__ == "__main__":
