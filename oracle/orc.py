@@ -58,7 +58,7 @@ class Radial(C.Structure):
 class Medium(C.Structure):
     _fields_ = [("kind", C.c_int), ("sp", SinProd), ("N", C.c_int), ("ext", C.c_double),
                 ("eval", C.c_void_p), ("grad", C.c_void_p), ("p", C.c_void_p), ("arith", C.c_int),
-                ("rad", Radial)]
+                ("rad", Radial), ("trig", C.c_int)]
 
 
 def build():
@@ -176,35 +176,52 @@ def radial_grid(terms, N, ext):
     return c
 
 
-def _medium(med):
+def _medium(med, trig=0):
+    """trig: 0 = sin/cos of the host libm (as the reference calls its own), 1 = the reproducible flavour of
+    ray_oracle.c, the sequence the HIP kernels evaluate (analytic media and the initial directions)."""
     if isinstance(med, tuple) and med and isinstance(med[0], tuple):
-        return radial_medium(med)
-    if isinstance(med, GridTables):
-        return med.medium()
-    if isinstance(med, Medium):
-        return med
-    return analytic_medium(med)
+        m = radial_medium(med)
+    elif isinstance(med, GridTables):
+        m = med.medium()
+    elif isinstance(med, Medium):
+        m = med
+    else:
+        m = analytic_medium(med)
+    m.trig = int(trig)
+    return m
 
 
-def init_states(med, ns, nd, dir_lo=0.0, dir_hi=np.pi, src_begin=0, src_end=None):
+def rep_sincos(a):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_rep_sincos(C.c_double(a), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def rep_shift(s0, c0, d):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_rep_shift(C.c_double(s0), C.c_double(c0), C.c_double(d), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def init_states(med, ns, nd, dir_lo=0.0, dir_hi=np.pi, src_begin=0, src_end=None, trig=0):
     src_end = ns if src_end is None else src_end
     num = (src_end - src_begin) * nd
     m = np.zeros((num, 9), dtype=np.float64, order="F")
-    mm = _medium(med)
+    mm = _medium(med, trig)
     lib().orc_init_states(C.byref(mm), C.c_int(ns), C.c_int(nd), C.c_double(dir_lo),
                           C.c_double(dir_hi), C.c_int(src_begin), C.c_int(src_end), _dp(m),
                           C.c_int64(num))
     return m
 
 
-def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=1):
+def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=1, trig=0):
     """In-place on m (Fortran (num,9)); returns (status, nsteps, nreflect)."""
     assert m.flags.f_contiguous and m.dtype == np.float64 and m.shape[1] == 9
     num = m.shape[0]
     st = np.zeros(num, dtype=np.int32)
     ns_ = np.zeros(num, dtype=np.int32)
     nr = np.zeros(num, dtype=np.int32)
-    mm = _medium(med)
+    mm = _medium(med, trig)
     ob = _obstacle(obstacle_r0)
     lib().orc_shoot(C.byref(mm), C.byref(ob), C.c_double(dt), C.c_int(time_unit),
                     C.c_int(max_steps), _dp(m), C.c_int64(num), C.c_int64(num), _dp(st), _dp(ns_),
@@ -213,9 +230,9 @@ def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=
 
 
 def scatter_relation(med, ns, nd, dt, dir_lo=0.0, dir_hi=np.pi, obstacle_r0=None, time_unit=0,
-                     src_begin=0, src_end=None, max_steps=100000, nthreads=1):
-    m = init_states(med, ns, nd, dir_lo, dir_hi, src_begin, src_end)
-    st, nsteps, nref = shoot(med, m, dt, obstacle_r0, time_unit, max_steps, nthreads)
+                     src_begin=0, src_end=None, max_steps=100000, nthreads=1, trig=0):
+    m = init_states(med, ns, nd, dir_lo, dir_hi, src_begin, src_end, trig)
+    st, nsteps, nref = shoot(med, m, dt, obstacle_r0, time_unit, max_steps, nthreads, trig)
     return m, st, nsteps, nref
 
 

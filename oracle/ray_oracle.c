@@ -241,17 +241,88 @@ static double grid_speed(double x, double y, const double *eval, const double *p
     return zdot(dx, dy, dx * dy, eval, (I - 1) + (J - 1) * n1, n1 * n1, 0);
 }
 
-/* a12 media (NonObstacleDemo.jl:12,23; ObstacleDemo.jl:12,18) */
-static double sinprod_c(const orc_sinprod *sp, double x, double y)
+/* ---- "reproducible" sin/cos flavour (med->trig == 1) ---------------------------------------------
+ * The reference calls Julia's sin and cos; any two math libraries differ in the last bit here and there,
+ * and on the analytic media that is the only thing between the HIP kernels and this file.  This flavour
+ * fixes one evaluation as a sequence of single IEEE roundings (+, -, *, fma, rint) -- the classical
+ * one: Cody-Waite reduction by pi/2 (a 33-bit head, so that n * head is exact), then the minimax
+ * polynomials for sin and cos on [-pi/4, pi/4] with a two-double argument (Sun fdlibm's published
+ * coefficients).  Within 1 ulp of the exact value for |a| <= 100 (tests/test_trig.py), i.e. the same
+ * class of difference as between two libms; the kernels evaluate the same sequence, so under this
+ * flavour analytic media compare bit for bit.  |a| >= 2^18, inf, NaN: libm (not reproducible; nothing
+ * in the unit disk gets there).
+ * Inside an RK4 step stages 2-4 advance the first stage's (sin, cos) by the small difference d of the
+ * arguments (angle addition with Taylor sums of sin d and 1 - cos d, |d| <= 1/4; beyond: the full
+ * evaluation): absolute error 1.6e-16 measured, against the 1.1e-16 of a correctly rounded value.   */
+static const double REP_BOUND = 262144.0, REP_SHIFT_MAX = 0.25;
+static void rep_kernel(double y, double t, double *sn, double *cs)
 {
-    return 1 + sp->A * sin(sp->wx * x) * sin(sp->wy * y);
+    static const double S[6] = {-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                                2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10};
+    static const double Cc[6] = {4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                                 -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+    double z = y * y, v = z * y;
+    double r = S[5];
+    for (int k = 4; k >= 1; --k) r = fma(z, r, S[k]);
+    double u = fma(-v, r, 0.5 * t);
+    u = fma(z, u, -t);
+    u = fma(-v, S[0], u);
+    *sn = y - u;
+    double q = Cc[5];
+    for (int k = 4; k >= 0; --k) q = fma(z, q, Cc[k]);
+    q = z * q;
+    double hz = 0.5 * z, w = 1.0 - hz;
+    *cs = w + (((1.0 - w) - hz) + fma(z, q, -(y * t)));
+}
+void orc_rep_sincos(double a, double *sn, double *cs)
+{
+    if (!(fabs(a) < REP_BOUND)) { *sn = sin(a); *cs = cos(a); return; }
+    double fn = rint(a * 6.36619772367581382433e-01);
+    int n = (int)fn;
+    double r = fma(-fn, 1.57079632673412561417e+00, a);         /* exact */
+    double w = fn * 6.07710050650619224932e-11;
+    double y = r - w, t = (r - y) - w;
+    double ks, kc;
+    rep_kernel(y, t, &ks, &kc);
+    double ss = (n & 1) ? kc : ks, cc = (n & 1) ? ks : kc;
+    *sn = (n & 2) ? -ss : ss;
+    *cs = ((n + 1) & 2) ? -cc : cc;
+}
+void orc_rep_shift(double s0, double c0, double d, double *sn, double *cs)
+{
+    static const double Ts[5] = {-1.66666666666666666667e-01, 8.33333333333333333333e-03, -1.98412698412698412698e-04,
+                                 2.75573192239858906526e-06, -2.50521083854417187751e-08};
+    static const double Tc[6] = {0.5, -4.16666666666666666667e-02, 1.38888888888888888889e-03, -2.48015873015873015873e-05,
+                                 2.75573192239858906526e-07, -2.08767569878680989792e-09};
+    double z = d * d;
+    double ps = Ts[4];
+    for (int k = 3; k >= 0; --k) ps = fma(z, ps, Ts[k]);
+    double sd = d + (d * z) * ps;                                 /* sin d */
+    double pc = Tc[5];
+    for (int k = 4; k >= 0; --k) pc = fma(z, pc, Tc[k]);
+    double v = z * pc;                                            /* 1 - cos d */
+    *sn = s0 + fma(c0, sd, -(s0 * v));
+    *cs = c0 - fma(s0, sd, c0 * v);
+}
+static double med_sin(const orc_medium *med, double a)
+{
+    if (!med->trig) return sin(a);
+    double s, c;
+    orc_rep_sincos(a, &s, &c);
+    return s;
+}
+
+/* a12 media (NonObstacleDemo.jl:12,23; ObstacleDemo.jl:12,18) */
+static double sinprod_c(const orc_medium *med, double x, double y)
+{
+    const orc_sinprod *sp = &med->sp;
+    return 1 + sp->A * med_sin(med, sp->wx * x) * med_sin(med, sp->wy * y);
 }
 
 /* a1: Hamilton (NonObstacle.jl:1-4):  [speed^2 * p ; -(p'p) * gradc * speed] */
-void orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4])
+static void hamilton_from_trig(const double X[4], const orc_sinprod *sp, double sx, double cx, double sy, double cy,
+                               double H[4])
 {
-    double sx = sin(sp->wx * X[0]), cx = cos(sp->wx * X[0]);
-    double sy = sin(sp->wy * X[1]), cy = cos(sp->wy * X[1]);
     double speed = 1 + sp->A * sx * sy;
     double g0 = sp->gx * (cx * sy);
     double g1 = sp->gy * (sx * cy);
@@ -262,37 +333,67 @@ void orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4])
     H[2] = ((-tau) * g0) * speed;
     H[3] = ((-tau) * g1) * speed;
 }
+void orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4])
+{
+    double sx = sin(sp->wx * X[0]), cx = cos(sp->wx * X[0]);
+    double sy = sin(sp->wy * X[1]), cy = cos(sp->wy * X[1]);
+    hamilton_from_trig(X, sp, sx, cx, sy, cy, H);
+}
+/* the reproducible flavour: stage 0 evaluates and remembers (argument, sin, cos) per coordinate in base[6],
+ * stages 1..3 advance from it */
+static void rep_stage(int stage, double a, double base[3], double *sn, double *cs)
+{
+    if (stage == 0) {
+        orc_rep_sincos(a, sn, cs);
+        base[0] = a; base[1] = *sn; base[2] = *cs;
+        return;
+    }
+    double d = a - base[0];
+    if (fabs(d) <= REP_SHIFT_MAX) orc_rep_shift(base[1], base[2], d, sn, cs);
+    else orc_rep_sincos(a, sn, cs);
+}
+static void hamilton_sinprod_rep(const double X[4], const orc_sinprod *sp, int stage, double base[6], double H[4])
+{
+    double sx, cx, sy, cy;
+    rep_stage(stage, sp->wx * X[0], base, &sx, &cx);
+    rep_stage(stage, sp->wy * X[1], base + 3, &sy, &cy);
+    hamilton_from_trig(X, sp, sx, cx, sy, cy, H);
+}
 
 /* a12 alternates (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), left to right as written:
  *   1.0 + 0.2 * sin(pi * r) + 0.4 * sin(pi * v) + ...
  *   0.2 * pi * cos(pi * r)/r * [(x-0.5), (y-0.2)] + 0.4 * pi * cos(pi * v)/v * [...] + ...        */
-static double radial_c(const orc_radial *rd, double x, double y)
+static double radial_c(const orc_medium *med, double x, double y)
 {
+    const orc_radial *rd = &med->rad;
     double c = 1.0;
     for (int k = 0; k < rd->K; ++k) {
         double dx = x - rd->x[k], dy = y - rd->y[k];
         double r = sqrt(dx * dx + dy * dy);
-        c = c + rd->a[k] * sin(M_PI * r);
+        c = c + rd->a[k] * med_sin(med, M_PI * r);
     }
     return c;
 }
-static void radial_grad(const orc_radial *rd, double x, double y, double g[2])
+static void radial_grad(const orc_medium *med, double x, double y, double g[2])
 {
+    const orc_radial *rd = &med->rad;
     g[0] = g[1] = 0;
     for (int k = 0; k < rd->K; ++k) {
         double dx = x - rd->x[k], dy = y - rd->y[k];
         double r = sqrt(dx * dx + dy * dy);
-        double f = ((rd->a[k] * M_PI) * cos(M_PI * r)) / r;
+        double cs = cos(M_PI * r), sn;
+        if (med->trig) orc_rep_sincos(M_PI * r, &sn, &cs);
+        double f = ((rd->a[k] * M_PI) * cs) / r;
         if (k == 0) { g[0] = f * dx; g[1] = f * dy; }
         else { g[0] = g[0] + f * dx; g[1] = g[1] + f * dy; }
     }
 }
 /* a1: Hamilton (NonObstacle.jl:1-4) with those closures */
-void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
+static void hamilton_radial(const double X[4], const orc_medium *med, double H[4])
 {
-    double speed = radial_c(rd, X[0], X[1]);
+    double speed = radial_c(med, X[0], X[1]);
     double g[2];
-    radial_grad(rd, X[0], X[1], g);
+    radial_grad(med, X[0], X[1], g);
     double tau = X[2] * X[2] + X[3] * X[3];
     double s2 = speed * speed;
     H[0] = s2 * X[2];
@@ -301,10 +402,21 @@ void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
     H[3] = ((-tau) * g[1]) * speed;
 }
 
-static int rhs(const orc_medium *med, const double X[4], double H[4])
+void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
 {
+    orc_medium med;
+    memset(&med, 0, sizeof med);
+    med.kind = 2;
+    med.rad = *rd;
+    hamilton_radial(X, &med, H);
+}
+
+/* stage = 0..3 inside an RK4 step, base = the step's scratch (the reproducible sinprod flavour only) */
+static int rhs(const orc_medium *med, const double X[4], double H[4], int stage, double base[6])
+{
+    if (med->kind == 0 && med->trig) { hamilton_sinprod_rep(X, &med->sp, stage, base, H); return 0; }
     if (med->kind == 0) { orc_hamilton_sinprod(X, &med->sp, H); return 0; }
-    if (med->kind == 2) { orc_hamilton_radial(X, &med->rad, H); return 0; }
+    if (med->kind == 2) { hamilton_radial(X, med, H); return 0; }
     return orc_discrete_hamilton(X, med->eval, med->grad, med->p, med->N, H);
 }
 
@@ -318,17 +430,20 @@ void orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, doubl
     orc_linspace(dir_lo, dir_hi, nd + 2, direct);
     for (int i = src_begin; i < src_end; ++i) {
         double sx = cos(source[i]), sy = sin(source[i]);
+        if (med->trig) orc_rep_sincos(source[i], &sy, &sx);
         int oob = 0;
-        double cs = med->kind == 0 ? sinprod_c(&med->sp, sx, sy)
-                  : med->kind == 2 ? radial_c(&med->rad, sx, sy)
+        double cs = med->kind == 0 ? sinprod_c(med, sx, sy)
+                  : med->kind == 2 ? radial_c(med, sx, sy)
                                    : grid_speed(sx, sy, med->eval, med->p, med->N, &oob);
         for (int j = 0; j < nd; ++j) {
             double theta = source[i] + M_PI * 0.5 + direct[j + 1];
             int64_t r = (int64_t)(i - src_begin) * nd + j;
             m[r + 0 * ld] = sx;
             m[r + 1 * ld] = sy;
-            m[r + 2 * ld] = cos(theta) / cs;
-            m[r + 3 * ld] = sin(theta) / cs;
+            double ct = cos(theta), st = sin(theta);
+            if (med->trig) orc_rep_sincos(theta, &st, &ct);
+            m[r + 2 * ld] = ct / cs;
+            m[r + 3 * ld] = st / cs;
         }
     }
     free(source);
@@ -384,17 +499,17 @@ void orc_ob_normal(const orc_obstacle *ob, double x, double y, double n[2]) { ob
  * (NonObstacle.jl:72-76; Obstacle.jl:34-38) */
 static int rk4_step_kdt(const orc_medium *med, double X[4], double dt)
 {
-    double k1[4], k2[4], k3[4], k4[4], Y[4], H[4];
+    double k1[4], k2[4], k3[4], k4[4], Y[4], H[4], base[6];
     int oob = 0;
     if (med->kind == 1 && med->arith == 1)
         return rk4_step_fused(med->eval, med->grad, med->p, med->N, X, dt);
-    oob |= rhs(med, X, H);
+    oob |= rhs(med, X, H, 0, base);
     for (int k = 0; k < 4; ++k) { k1[k] = H[k] * dt; Y[k] = X[k] + k1[k] / 2; }
-    oob |= rhs(med, Y, H);
+    oob |= rhs(med, Y, H, 1, base);
     for (int k = 0; k < 4; ++k) { k2[k] = H[k] * dt; Y[k] = X[k] + k2[k] / 2; }
-    oob |= rhs(med, Y, H);
+    oob |= rhs(med, Y, H, 2, base);
     for (int k = 0; k < 4; ++k) { k3[k] = H[k] * dt; Y[k] = X[k] + k3[k]; }
-    oob |= rhs(med, Y, H);
+    oob |= rhs(med, Y, H, 3, base);
     for (int k = 0; k < 4; ++k) {
         k4[k] = H[k] * dt;
         X[k] = X[k] + (((k1[k] + 2 * k2[k]) + 2 * k3[k]) + k4[k]) / 6.0;

@@ -66,6 +66,9 @@ typedef struct {
     const double *eval, *grad, *p;
     int arith;             /* grid only: 0 = as written (un-fused), 1 = "fused" flavour (ray_oracle.c) */
     orc_radial rad;
+    int trig;              /* sin/cos of the analytic media and of the initial directions: 0 = the host libm (the
+                              reference calls Julia's sin/cos), 1 = the "reproducible" flavour (ray_oracle.c: a fixed
+                              sequence of +,-,*,fma -- what the HIP kernels evaluate, the same bits on any machine) */
 } orc_medium;
 
 void   orc_linspace(double a, double b, int n, double *out);
@@ -79,6 +82,10 @@ void   orc_hamilton_sinprod(const double X[4], const orc_sinprod *sp, double H[4
 void   orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4]);
 
 /* initial boundary phase-space grid, rows for sources [src_begin, src_end) */
+/* the reproducible flavour's building blocks, exported for the CPU tests that measure them against long double */
+void   orc_rep_sincos(double a, double *s, double *c);
+void   orc_rep_shift(double s0, double c0, double d, double *s, double *c);
+
 void   orc_init_states(const orc_medium *med, int ns, int nd, double dir_lo, double dir_hi,
                        int src_begin, int src_end, double *m, int64_t ld);
 

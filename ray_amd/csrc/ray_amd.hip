@@ -90,7 +90,7 @@ struct ShootArgs {
     int ngroup;             // source groups per direction chunk = ceil(nsrc / (waves per block * sources per wave))
     int dshift;             // log2 of the directions per wave: a wave is 2^(6-dshift) sources x 2^dshift directions
     const double *src;      // source[i]            (local index i - src_begin)
-    const double *src_cos;  // cos(source[i])  host libm
+    const double *src_cos;  // cos(source[i])  (host, ray_trig.h)
     const double *src_sin;  // sin(source[i])
     const double *direct;   // direct[j], j = 0..nd-1
     double half_pi;         // Float64(pi) * 0.5
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
             const double sx = a.src_cos[il], sy = a.src_sin[il];
             const double theta = a.src[il] + a.half_pi + a.direct[j];
             double sn, cs;
-            sincos(theta, &sn, &cs);
+            sincos_rep(theta, sn, cs);
             const double c0 = (MED == kGrid) ? speed_grid(a.med.g, AR == kExact ? lds_nodes() : a.med.g.p, sx, sy, oob)
                             : (MED == kRadial) ? speed_radial(a.med.rd, sx, sy)
                                              : speed_sinprod(a.med.sp, sx, sy);
@@ -784,8 +784,7 @@ struct InitTables {
         std::vector<double> s(nloc), c(nloc), sn_(nloc);
         for (int i = 0; i < nloc; ++i) {
             s[i] = source[p->src_begin + i * st];
-            c[i] = std::cos(s[i]);                                        // NonObstacle.jl:57
-            sn_[i] = std::sin(s[i]);
+            trig::sincos_bounded(s[i], sn_[i], c[i]);                      // NonObstacle.jl:57 (ray_trig.h: 0 <= s <= 2 pi)
         }
         HIPCHK(src.alloc(sizeof(double) * nloc));
         HIPCHK(cs.alloc(sizeof(double) * nloc));

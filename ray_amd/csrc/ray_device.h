@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ray_trig.h"
 
 namespace ray {
 
@@ -496,12 +497,54 @@ __device__ __forceinline__ double speed_grid(const GridDev &g, const double *pt,
     return ((e01.x + dx * e01.y) + dy * e23.x) + (dx * dy) * e23.y;
 }
 
+// sin and cos as the analytic media and the initial directions take them: ray_trig.h's reproducible evaluation
+// inside its range, the platform's beyond (|a| >= 2^18, inf, NaN: nothing the unit disk produces)
+__device__ __forceinline__ void sincos_rep(double a, double &sn, double &cs)
+{
+    if (trig::in_range(a)) trig::sincos_bounded(a, sn, cs);
+    else sincos(a, &sn, &cs);
+}
+// the same out of line: the rare branches of the stepping loop call it instead of carrying a copy each
+__device__ __attribute__((noinline)) double2 sincos_rep_call(double a)
+{
+    double2 r;
+    sincos_rep(a, r.x, r.y);
+    return r;
+}
+__device__ __forceinline__ double sin_rep(double a)
+{
+    double sn, cs;
+    sincos_rep(a, sn, cs);
+    return sn;
+}
+
+// sin/cos of the step's first stage, from which the other three stages are advanced (trig::shift): their arguments
+// differ from the first stage's by w * (Y - X) = O(w dt c).  The difference of the two rounded arguments is taken
+// exactly as computed, so each stage still evaluates sin/cos of its own argument w * Y, to 1 ulp of 1.
+struct TrigBase {
+    double a0, sa, ca, b0, sb, cb;
+};
+template <int STAGE>
+__device__ __forceinline__ void sincos_stage(double a, double &base_a, double &base_s, double &base_c, double &sn, double &cs)
+{
+    if (STAGE == 0) {
+        if (trig::in_range(a)) trig::sincos_bounded(a, sn, cs);
+        else { const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y; }
+        base_a = a; base_s = sn; base_c = cs;
+    } else {
+        const double d = a - base_a;
+        if (__builtin_fabs(d) <= trig::kShiftMax) trig::shift(base_s, base_c, d, sn, cs);
+        else { const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y; }
+    }
+}
+
 // a1: Hamilton with the analytic sin-product medium                  NonObstacle.jl:1-4
-__device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4])
+template <int STAGE>
+__device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4], TrigBase &tb)
 {
     double sx, cx, sy, cy;
-    sincos(s.wx * X[0], &sx, &cx);
-    sincos(s.wy * X[1], &sy, &cy);
+    sincos_stage<STAGE>(s.wx * X[0], tb.a0, tb.sa, tb.ca, sx, cx);
+    sincos_stage<STAGE>(s.wy * X[1], tb.b0, tb.sb, tb.cb, sy, cy);
     const double speed = 1 + s.A * sx * sy;
     const double g0 = s.gx * (cx * sy);
     const double g1 = s.gy * (sx * cy);
@@ -514,7 +557,7 @@ __device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[
 }
 __device__ __forceinline__ double speed_sinprod(const SinProdDev &s, double x, double y)
 {
-    return 1 + s.A * sin(s.wx * x) * sin(s.wy * y);
+    return 1 + s.A * sin_rep(s.wx * x) * sin_rep(s.wy * y);
 }
 
 // a1 with the commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), as written:
@@ -530,7 +573,7 @@ __device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4
             const double dx = X[0] - rd.x[k], dy = X[1] - rd.y[k];
             const double r = __builtin_sqrt(dx * dx + dy * dy);
             double sn, cs;
-            sincos(kPi * r, &sn, &cs);
+            sincos_rep(kPi * r, sn, cs);
             speed = speed + rd.a[k] * sn;
             const double f = ((rd.a[k] * kPi) * cs) / r;
             if (k == 0) { g0 = f * dx; g1 = f * dy; }
@@ -549,7 +592,7 @@ __device__ __forceinline__ double speed_radial(const RadialDev &rd, double x, do
     double speed = 1.0;
     for (int k = 0; k < rd.K; ++k) {
         const double dx = x - rd.x[k], dy = y - rd.y[k];
-        speed = speed + rd.a[k] * sin(kPi * __builtin_sqrt(dx * dx + dy * dy));
+        speed = speed + rd.a[k] * sin_rep(kPi * __builtin_sqrt(dx * dx + dy * dy));
     }
     return speed;
 }
@@ -560,13 +603,13 @@ struct MediumDev {
     RadialDev rd;
 };
 
-template <int MED, int AR, int MODE = kFetch>
+template <int MED, int AR, int MODE = kFetch, int STAGE = 0>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob,
-                                    unsigned long long lm, RecState &rs)
+                                    unsigned long long lm, RecState &rs, TrigBase &tb)
 {
     if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm, rs);
     else if (MED == kRadial) rhs_radial(m.rd, X, H);
-    else rhs_sinprod(m.sp, X, H);
+    else rhs_sinprod<STAGE>(m.sp, X, H, tb);
 }
 
 // fma with a destination of its own (v_fma_f64): the stage update Y = X + H*hdt must leave X alive, and
@@ -587,45 +630,46 @@ __device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const
                                     unsigned long long lm, OobMax &oob, RecState &rs)
 {
     double H[4], Y[4], acc[4];
+    TrigBase tb;
     if (AR == kFused && MED == kGrid) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR, kLookup>(m, pt, X, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kLookup>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR, kFetch>(m, pt, Y, H, oob, lm, rs);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }
