@@ -105,7 +105,11 @@ int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
  *                              them out (NonObstacle.jl:63).  The trace kernel then walks them like the shooting
  *                              kernel does -- waves of 2 adjacent sources x 32 directions, longest chords first, XCD
  *                              arcs -- instead of 64 consecutive rows per wave: same results, row for row and bit for
- *                              bit, 1.5x the rate on a 2048 x 2048 sweep.  Ignored when num is not a multiple of nd.   */
+ *                              bit, 1.5x the rate on a 2048 x 2048 sweep.  Ignored when num is not a multiple of nd.
+ *                              With the option at 0 the host-pointer entry points (ray_trace_fixed_time,
+ *                              ray_trace_paths) look for such fans in m themselves -- runs of equal length with one
+ *                              starting point each -- so the reference's own call NonReflectionTrace(c, m, ext, dt)
+ *                              (Obstacle.jl:275) needs no hint; the _dev entry points take m as it is told.         */
 #define RAY_OPT_FAN_DIRECTIONS 3
 int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
 /* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by

@@ -1366,9 +1366,27 @@ int ray_shoot_paths(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
 }
 
 // ---- fixed-time trace -------------------------------------------------------------------------------
+// The rows of a host `m` as fans: nd when they are runs of nd rows with one starting point each (what ScatterRelation
+// returns and the reference's callers pass on: NonObstacle.jl:63, Obstacle.jl:275), else 0.  Looks at the first run and
+// at the two ends of every other one: the answer only chooses the trace kernel's work mapping, never its results.
+static int detect_fan(const double *m, int64_t num, int64_t ld)
+{
+    const double *x = m, *y = m + ld;
+    int64_t nd = 1;
+    while (nd < num && x[nd] == x[0] && y[nd] == y[0]) ++nd;
+    if (nd < 2 || nd > INT32_MAX || num % nd) return 0;
+    for (int64_t f = nd; f < num; f += nd) {
+        const int64_t l = f + nd - 1;
+        if (x[f] != x[l] || y[f] != y[l] || (x[f] == x[f - 1] && y[f] == y[f - 1])) return 0;
+    }
+    return (int)nd;
+}
+
+// fan: rows per fan for k_shoot's work mapping (RAY_OPT_FAN_DIRECTIONS or detect_fan), 0 = one lane per row in order
 static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_dev, int64_t num,
                           int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
-                          int32_t *status_dev, int32_t *nsteps_dev, double *path_dev, int32_t *npts_dev, int max_pts)
+                          int32_t *status_dev, int32_t *nsteps_dev, double *path_dev, int32_t *npts_dev, int max_pts,
+                          int fan)
 {
     int rc = use(ctx);
     if (rc) return rc;
@@ -1386,10 +1404,10 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     a.X = X_dev; a.ldx = ldx; a.status = status_dev; a.nsteps = nsteps_dev;
     a.step_counter = ctx->d_steps;
     unsigned nblk = (unsigned)((num + block_threads() - 1) / block_threads());
-    if (ctx->fan_nd > 0 && num % ctx->fan_nd == 0) {        // the rows are fans of fan_nd directions: k_shoot's mapping
+    if (fan > 0 && num % fan == 0) {                        // the rows are fans of `fan` directions: k_shoot's mapping
         const int wpb = block_threads() / 64;
-        a.nd = ctx->fan_nd;
-        a.nsrc = (int)(num / ctx->fan_nd);
+        a.nd = fan;
+        a.nsrc = (int)(num / fan);
         int dshift = 5;
         while (dshift > 2 && (1 << (dshift - 1)) >= a.nd) --dshift;
         a.dshift = dshift;
@@ -1417,7 +1435,8 @@ int ray_trace_fixed_time_dev(ray_ctx *ctx, const ray_medium *med, const double *
                              int64_t ld, double dt, int32_t mode, double *X_dev, int64_t ldx,
                              int32_t *status_dev, int32_t *nsteps_dev)
 {
-    return trace_dev_impl(ctx, med, m_dev, num, ld, dt, mode, X_dev, ldx, status_dev, nsteps_dev, nullptr, nullptr, 0);
+    return trace_dev_impl(ctx, med, m_dev, num, ld, dt, mode, X_dev, ldx, status_dev, nsteps_dev, nullptr, nullptr, 0,
+                          ctx ? ctx->fan_nd : 0);
 }
 
 int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_host, int64_t num,
@@ -1435,8 +1454,9 @@ int ray_trace_fixed_time(ray_ctx *ctx, const ray_medium *med, const double *m_ho
     if ((rc = ob_.alloc(num))) return rc;
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
-    rc = ray_trace_fixed_time_dev(ctx, med, dm.as<double>(), num, num, dt, mode, dX.as<double>(), num,
-                                  ob_.st.as<int32_t>(), ob_.ns.as<int32_t>());
+    rc = trace_dev_impl(ctx, med, dm.as<double>(), num, num, dt, mode, dX.as<double>(), num,
+                        ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), nullptr, nullptr, 0,
+                        ctx->fan_nd > 0 ? ctx->fan_nd : detect_fan(m_host, num, ld));
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
     if ((rc = ob_.fetch(ctx, num, status, nsteps, nullptr))) return rc;
@@ -1467,7 +1487,8 @@ int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, i
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 0, 4))) return rc;
     if ((rc = copy_cols_h2d(ctx, dm.as<double>(), num, m_host, ld, num, 8, 1))) return rc;
     rc = trace_dev_impl(ctx, med, dm.as<double>(), num, num, dt, mode, dX.as<double>(), num,
-                        ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), dpath.as<double>(), dnp.as<int32_t>(), max_pts);
+                        ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), dpath.as<double>(), dnp.as<int32_t>(), max_pts,
+                        ctx->fan_nd > 0 ? ctx->fan_nd : detect_fan(m_host, num, ld));
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if ((rc = copy_cols_d2h(ctx, X_host, ldx, dX.as<double>(), num, num, 0, 4))) return rc;
     HIPCHK(hipMemcpyAsync(path_host, dpath.p, pbytes, hipMemcpyDeviceToHost, ctx->stream));

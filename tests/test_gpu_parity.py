@@ -402,31 +402,37 @@ def test_trace_vs_oracle_bit_exact(ctx, orc, arith, N, ns, nd, mode):
 
 @pytest.mark.parametrize("ns,nd", [(37, 100), (64, 32), (9, 7), (3, 301), (130, 2)])
 def test_trace_fan_hint_changes_nothing(ctx, orc, arith, ns, nd):
-    """RAY_OPT_FAN_DIRECTIONS only remaps rays to lanes: hinted traces equal unhinted ones bit for bit (both
-    modes, the polyline variant too), for fan widths that do not fill a wave's direction patch and source
-    counts that do not fill a workgroup, and a hint that does not divide the row count is ignored."""
+    """RAY_OPT_FAN_DIRECTIONS -- or the fans the host-pointer entry points recognise by themselves in m -- only remap
+    rays to lanes: such traces equal the row-ordered ones bit for bit (both modes, the polyline variant too), for fan
+    widths that do not fill a wave's direction patch and source counts that do not fill a workgroup; a hint that does
+    not divide the row count is ignored.  Row order is forced by tracing a shuffled copy of the rows (no fans in it)."""
     import ray_amd
     from ray_amd import _lib
     N = 45
     data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, nthreads=4)
     c0 = np.asfortranarray(0.85 * orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) + 0.1)
     med = ray_amd.GridMedium(c0, 1.5, ctx)
+    perm = np.random.default_rng(ns * 1000 + nd).permutation(ns * nd)
+    shuffled = np.asfortranarray(data[perm])
     for mode in (0, 1):
-        X0, i0 = ray_amd._trace(med, data, 1.5, 5e-2, mode, ctx, True)
-        X1, i1 = ray_amd._trace(med, data, 1.5, 5e-2, mode, ctx, True, nd=nd)
-        assert np.array_equal(X0, X1)
-        assert np.array_equal(i0["status"], i1["status"]) and np.array_equal(i0["nsteps"], i1["nsteps"])
-        if ns * nd > 1:                                     # a hint that does not fit the rows: ignored
-            X2, i2 = ray_amd._trace(med, data, 1.5, 5e-2, mode, ctx, True, nd=ns * nd - 1)
-            assert np.array_equal(X0, X2) and np.array_equal(i0["nsteps"], i2["nsteps"])
-    p0, j0 = ray_amd.NonReflectionPlot(med, data, 1.5, 5e-2, ctx=ctx, info=True)
+        Xs, i_s = ray_amd._trace(med, shuffled, 1.5, 5e-2, mode, ctx, True)
+        X0 = np.empty_like(Xs); X0[perm] = Xs
+        n0 = np.empty_like(i_s["nsteps"]); n0[perm] = i_s["nsteps"]
+        s0 = np.empty_like(i_s["status"]); s0[perm] = i_s["status"]
+        for hint in (0, nd, ns * nd - 1 if ns * nd > 1 else 0):       # recognised / told / a hint that does not fit
+            X1, i1 = ray_amd._trace(med, data, 1.5, 5e-2, mode, ctx, True, nd=hint)
+            assert np.array_equal(X0, X1)
+            assert np.array_equal(s0, i1["status"]) and np.array_equal(n0, i1["nsteps"])
+    ps, js = ray_amd.NonReflectionPlot(med, shuffled, 1.5, 5e-2, ctx=ctx, info=True)
+    p1, j1 = ray_amd.NonReflectionPlot(med, data, 1.5, 5e-2, ctx=ctx, info=True)
     ctx.set_option(_lib.OPT_FAN_DIRECTIONS, nd)
     try:
-        p1, j1 = ray_amd.NonReflectionPlot(med, data, 1.5, 5e-2, ctx=ctx, info=True)
+        p2, j2 = ray_amd.NonReflectionPlot(med, data, 1.5, 5e-2, ctx=ctx, info=True)
     finally:
         ctx.set_option(_lib.OPT_FAN_DIRECTIONS, 0)
-    assert len(p0) == len(p1) and all(np.array_equal(a, b) for a, b in zip(p0, p1))
-    assert np.array_equal(j0["X"], j1["X"]) and np.array_equal(j0["npts"], j1["npts"])
+    for p, j in ((p1, j1), (p2, j2)):
+        assert len(p) == len(ps) and all(np.array_equal(ps[k], p[perm[k]]) for k in range(len(ps)))
+        assert np.array_equal(js["X"], j["X"][perm]) and np.array_equal(js["npts"], j["npts"][perm])
 
 
 def test_trace_cease_and_oob_flags(ctx, orc, arith):
