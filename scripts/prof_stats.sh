@@ -7,6 +7,6 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
-    python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+    python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "stats rc=$?"
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cat {} \; | head -20
