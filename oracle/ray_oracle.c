@@ -374,6 +374,28 @@ static double radial_c(const orc_medium *med, double x, double y)
     }
     return c;
 }
+/* reproducible flavour inside an RK4 step: sin and cos of pi r_k by stage (rep_stage), base + 3k per term */
+static void hamilton_radial_rep(const double X[4], const orc_medium *med, int stage, double base[12], double H[4])
+{
+    const orc_radial *rd = &med->rad;
+    double speed = 1.0, g[2] = {0, 0};
+    for (int k = 0; k < rd->K; ++k) {
+        double dx = X[0] - rd->x[k], dy = X[1] - rd->y[k];
+        double r = sqrt(dx * dx + dy * dy);
+        double sn, cs;
+        rep_stage(stage, M_PI * r, base + 3 * k, &sn, &cs);
+        speed = speed + rd->a[k] * sn;
+        double f = ((rd->a[k] * M_PI) * cs) / r;
+        if (k == 0) { g[0] = f * dx; g[1] = f * dy; }
+        else { g[0] = g[0] + f * dx; g[1] = g[1] + f * dy; }
+    }
+    double tau = X[2] * X[2] + X[3] * X[3];
+    double s2 = speed * speed;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = ((-tau) * g[0]) * speed;
+    H[3] = ((-tau) * g[1]) * speed;
+}
 static void radial_grad(const orc_medium *med, double x, double y, double g[2])
 {
     const orc_radial *rd = &med->rad;
@@ -412,9 +434,10 @@ void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
 }
 
 /* stage = 0..3 inside an RK4 step, base = the step's scratch (the reproducible sinprod flavour only) */
-static int rhs(const orc_medium *med, const double X[4], double H[4], int stage, double base[6])
+static int rhs(const orc_medium *med, const double X[4], double H[4], int stage, double base[12])
 {
     if (med->kind == 0 && med->trig) { hamilton_sinprod_rep(X, &med->sp, stage, base, H); return 0; }
+    if (med->kind == 2 && med->trig) { hamilton_radial_rep(X, med, stage, base, H); return 0; }
     if (med->kind == 0) { orc_hamilton_sinprod(X, &med->sp, H); return 0; }
     if (med->kind == 2) { hamilton_radial(X, med, H); return 0; }
     return orc_discrete_hamilton(X, med->eval, med->grad, med->p, med->N, H);
@@ -499,7 +522,7 @@ void orc_ob_normal(const orc_obstacle *ob, double x, double y, double n[2]) { ob
  * (NonObstacle.jl:72-76; Obstacle.jl:34-38) */
 static int rk4_step_kdt(const orc_medium *med, double X[4], double dt)
 {
-    double k1[4], k2[4], k3[4], k4[4], Y[4], H[4], base[6];
+    double k1[4], k2[4], k3[4], k4[4], Y[4], H[4], base[12];
     int oob = 0;
     if (med->kind == 1 && med->arith == 1)
         return rk4_step_fused(med->eval, med->grad, med->p, med->N, X, dt);

@@ -522,7 +522,7 @@ __device__ __forceinline__ double sin_rep(double a)
 // differ from the first stage's by w * (Y - X) = O(w dt c).  The difference of the two rounded arguments is taken
 // exactly as computed, so each stage still evaluates sin/cos of its own argument w * Y, to 1 ulp of 1.
 struct TrigBase {
-    double a0, sa, ca, b0, sb, cb;
+    double a[kRadialMax], s[kRadialMax], c[kRadialMax];   // per argument: x and y of the sin-product, r_k of the radial sum
 };
 template <int STAGE>
 __device__ __forceinline__ void sincos_stage(double a, double &base_a, double &base_s, double &base_c, double &sn, double &cs)
@@ -543,8 +543,8 @@ template <int STAGE>
 __device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4], TrigBase &tb)
 {
     double sx, cx, sy, cy;
-    sincos_stage<STAGE>(s.wx * X[0], tb.a0, tb.sa, tb.ca, sx, cx);
-    sincos_stage<STAGE>(s.wy * X[1], tb.b0, tb.sb, tb.cb, sy, cy);
+    sincos_stage<STAGE>(s.wx * X[0], tb.a[0], tb.s[0], tb.c[0], sx, cx);
+    sincos_stage<STAGE>(s.wy * X[1], tb.a[1], tb.s[1], tb.c[1], sy, cy);
     const double speed = 1 + s.A * sx * sy;
     const double g0 = s.gx * (cx * sy);
     const double g1 = s.gy * (sx * cy);
@@ -563,7 +563,8 @@ __device__ __forceinline__ double speed_sinprod(const SinProdDev &s, double x, d
 // a1 with the commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), as written:
 //   c      = 1.0 + a1 * sin(pi * r1) + a2 * sin(pi * r2) + ...             r_k = sqrt((x-x_k)^2 + (y-y_k)^2)
 //   grad c = a1 * pi * cos(pi * r1)/r1 * [(x-x1), (y-y1)] + ...
-__device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4], double H[4])
+template <int STAGE>
+__device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4], double H[4], TrigBase &tb)
 {
     constexpr double kPi = 3.141592653589793;
     double speed = 1.0, g0 = 0, g1 = 0;
@@ -573,7 +574,7 @@ __device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4
             const double dx = X[0] - rd.x[k], dy = X[1] - rd.y[k];
             const double r = __builtin_sqrt(dx * dx + dy * dy);
             double sn, cs;
-            sincos_rep(kPi * r, sn, cs);
+            sincos_stage<STAGE>(kPi * r, tb.a[k], tb.s[k], tb.c[k], sn, cs);
             speed = speed + rd.a[k] * sn;
             const double f = ((rd.a[k] * kPi) * cs) / r;
             if (k == 0) { g0 = f * dx; g1 = f * dy; }
@@ -608,7 +609,7 @@ __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const
                                     unsigned long long lm, RecState &rs, TrigBase &tb)
 {
     if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm, rs);
-    else if (MED == kRadial) rhs_radial(m.rd, X, H);
+    else if (MED == kRadial) rhs_radial<STAGE>(m.rd, X, H, tb);
     else rhs_sinprod<STAGE>(m.sp, X, H, tb);
 }
 

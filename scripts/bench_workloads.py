@@ -81,6 +81,7 @@ def main():
     run("shoot grid512 smooth dt=h/2", shoot(gsmooth, None, 0, (p[1] - p[0]) / 2), "fused")
     run("shoot analytic smooth (NonObstacleDemo medium)", shoot(smooth, None, 0))
     run("shoot analytic obstacle circle0.3 (ObstacleDemo workload)", shoot(obst, circle, 1))
+    run("shoot analytic radial sine sum, 4 terms (NonObstacleDemo.jl:7-11 alternate)", shoot(ray_amd.RadialSineSum.smooth_alt(), None, 0))
     run("shoot grid512 obstacle circle0.3", shoot(gobst, circle, 1))
     run("shoot analytic obstacle trefoil 0.4/0.3/0.2 (ObstacleDemo.jl:23-24 alternate, cavities)", shoot(obst, trefoil, 1))
     run("shoot grid512 obstacle trefoil", shoot(gobst, trefoil, 1))
