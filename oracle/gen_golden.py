@@ -4,6 +4,7 @@ Run from the repo root:  python oracle/gen_golden.py            (all fixtures)
                          python oracle/gen_golden.py trefoil    (only the trefoil one, added later)
                          python oracle/gen_golden.py radial     (only the radial-sine-sum ones, added later)
                          python oracle/gen_golden.py trefoil_grid   (grid + trefoil "identity" flavour, round 2)
+                         python oracle/gen_golden.py rep        (analytic media, reproducible sin/cos flavour, round 2)
 The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
 path to the Python reading of the reference; the reference itself ships no vectors
 ("parity unpinned" by the reference).
@@ -68,8 +69,31 @@ def radial():
                  **pack(rows, P.shoot(med, rows, dt, obstacle=ob, time_unit=tu)))
 
 
+def rep():
+    # G1g: the shipped analytic media under the reproducible sin/cos flavour (ray_oracle.py rep_sincos / rep_shift:
+    #      the sequence of roundings the HIP kernels and the C oracle's trig = 1 evaluate) -- the smooth demo, and the
+    #      obstacle demo around the trefoil (identity flavour): no math library anywhere on these paths, so the C
+    #      oracle and the HIP kernels must reproduce every bit and every event
+    ns, nd, dt = 8, 16, 1e-2
+    sp = P.SinProd.smooth_demo()
+    sp.trig = "rep"
+    rows = P.init_states(sp, ns, nd, 0.0, pi)
+    np.savez(os.path.join(OUT, "scatter_smooth_rep_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt,
+             params=np.array([sp.A, sp.wx, sp.wy, sp.gx, sp.gy]), **pack(rows, P.shoot(sp, rows, dt)))
+    so = P.SinProd.obstacle_demo()
+    so.trig = "rep"
+    rows = P.init_states(so, ns, nd, 0.0, pi)
+    tf = P.Trefoil(0.4, 0.3, 0.2, trig="identity")
+    np.savez(os.path.join(OUT, "scatter_trefoil_rep_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt,
+             trefoil=np.array([tf.R, tf.rho, tf.rho_n]),
+             params=np.array([so.A, so.wx, so.wy, so.gx, so.gy]),
+             **pack(rows, P.shoot(so, rows, dt, obstacle=tf, time_unit=1)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["rep"]:
+        return rep()
     if sys.argv[1:] == ["trefoil"]:
         return trefoil()
     if sys.argv[1:] == ["radial"]:
@@ -79,6 +103,7 @@ def main():
     trefoil()
     trefoil_grid()
     radial()
+    rep()
     ns, nd, dt = 8, 16, 1e-2
 
     # G1a: smooth demo medium, analytic, ScatterRelation (NonObstacleDemo.jl:32)

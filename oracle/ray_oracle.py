@@ -25,12 +25,95 @@ def linspace(a, b, n):
     return [float(fa + (fb - fa) * (k - 1) / (n - 1)) for k in range(1, n + 1)]
 
 
+# ---- the "reproducible" sin/cos flavour (ray_oracle.c, med->trig == 1), read a second time ---------------
+# Every operation one IEEE rounding; fma through exact rationals (CPython has no fma before 3.13).
+def _fma(a, b, c):
+    return float(Fraction(a) * Fraction(b) + Fraction(c))       # Fraction -> float rounds correctly
+
+
+_S = [-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+      2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10]
+_C = [4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+      -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11]
+_TS = [-1 / 6, 1 / 120, -1 / 5040, 1 / 362880, -1 / 39916800]
+_TC = [0.5, -1 / 24, 1 / 720, -1 / 40320, 1 / 3628800, -1 / 479001600]
+REP_BOUND, REP_SHIFT_MAX = 262144.0, 0.25
+
+
+def rep_sincos(a):
+    """(sin a, cos a): Cody-Waite reduction by pi/2 (33-bit head) + fdlibm's polynomials on [-pi/4, pi/4]."""
+    if not abs(a) < REP_BOUND:
+        return sin(a), cos(a)
+    fn = float(round(Fraction(a * 6.36619772367581382433e-01)))     # to nearest, ties to even
+    n = int(fn)
+    r = _fma(-fn, 1.57079632673412561417e+00, a)
+    w = fn * 6.07710050650619224932e-11
+    y = r - w
+    t = (r - y) - w
+    z = y * y
+    v = z * y
+    p = _S[5]
+    for k in (4, 3, 2, 1):
+        p = _fma(z, p, _S[k])
+    u = _fma(-v, p, 0.5 * t)
+    u = _fma(z, u, -t)
+    u = _fma(-v, _S[0], u)
+    ks = y - u
+    q = _C[5]
+    for k in (4, 3, 2, 1, 0):
+        q = _fma(z, q, _C[k])
+    q = z * q
+    hz = 0.5 * z
+    ww = 1.0 - hz
+    kc = ww + (((1.0 - ww) - hz) + _fma(z, q, -(y * t)))
+    ss, cc = (kc, ks) if n & 1 else (ks, kc)
+    return (-ss if n & 2 else ss), (-cc if (n + 1) & 2 else cc)
+
+
+def rep_shift(s0, c0, d):
+    """(sin(a0 + d), cos(a0 + d)) from (sin a0, cos a0), |d| <= 1/4."""
+    z = d * d
+    ps = _TS[4]
+    for k in (3, 2, 1, 0):
+        ps = _fma(z, ps, _TS[k])
+    sd = d + (d * z) * ps
+    pc = _TC[5]
+    for k in (4, 3, 2, 1, 0):
+        pc = _fma(z, pc, _TC[k])
+    v = z * pc
+    return s0 + _fma(c0, sd, -(s0 * v)), c0 - _fma(s0, sd, c0 * v)
+
+
+def rep_stage(stage, a, base, slot):
+    """sin/cos of a at RK4 stage 0..3: stage 0 evaluates and remembers, the others advance from it."""
+    if stage == 0:
+        sn, cs = rep_sincos(a)
+        base[slot] = (a, sn, cs)
+        return sn, cs
+    a0, s0, c0 = base[slot]
+    d = a - a0
+    if abs(d) <= REP_SHIFT_MAX:
+        return rep_shift(s0, c0, d)
+    return rep_sincos(a)
+
+
 # ---- media (NonObstacleDemo.jl:12,23; ObstacleDemo.jl:12,18) --------------------------------
 class SinProd:
-    """c = 1 + A sin(wx x) sin(wy y);  grad c = [gx cos sin, gy sin cos]."""
+    """c = 1 + A sin(wx x) sin(wy y);  grad c = [gx cos sin, gy sin cos].
+    trig = "libm": math.sin/cos (as the reference calls its own); trig = "rep": the reproducible flavour above, the
+    sequence the HIP kernels evaluate (stages of an RK4 step through `hamilton_staged`)."""
 
-    def __init__(self, A, wx, wy, gx, gy):
-        self.A, self.wx, self.wy, self.gx, self.gy = A, wx, wy, gx, gy
+    def __init__(self, A, wx, wy, gx, gy, trig="libm"):
+        self.A, self.wx, self.wy, self.gx, self.gy, self.trig = A, wx, wy, gx, gy, trig
+
+    def hamilton_staged(self, X, stage, base):
+        sx, cx = rep_stage(stage, self.wx * X[0], base, 0)
+        sy, cy = rep_stage(stage, self.wy * X[1], base, 1)
+        speed = 1 + self.A * sx * sy
+        g = [self.gx * (cx * sy), self.gy * (sx * cy)]
+        tau = X[2] * X[2] + X[3] * X[3]
+        s2 = speed * speed
+        return [s2 * X[2], s2 * X[3], ((-tau) * g[0]) * speed, ((-tau) * g[1]) * speed], 0
 
     @staticmethod
     def smooth_demo():  # NonObstacleDemo.jl:12,23
@@ -41,6 +124,8 @@ class SinProd:
         return SinProd(0.2, 2 * pi, pi, 2 * (0.2 * pi), 0.2 * pi)
 
     def c(self, x, y):
+        if self.trig == "rep":
+            return 1 + self.A * rep_sincos(self.wx * x)[0] * rep_sincos(self.wy * y)[0]
         return 1 + self.A * sin(self.wx * x) * sin(self.wy * y)
 
     def gradc(self, x, y):
@@ -210,24 +295,33 @@ def init_states(med, ns, nd, dir_lo=0.0, dir_hi=pi, src_begin=0, src_end=None):
     source = linspace(0.0, 2 * pi, ns + 1)[:ns]
     direct = linspace(dir_lo, dir_hi, nd + 2)[1:nd + 1]
     rows = []
+    rep = getattr(med, "trig", "libm") == "rep"
     for i in range(src_begin, src_end):
         sx, sy = cos(source[i]), sin(source[i])
+        if rep:
+            sy, sx = rep_sincos(source[i])
         cs = med.c(sx, sy)
         for j in range(nd):
             theta = source[i] + pi * 0.5 + direct[j]
-            rows.append([sx, sy, cos(theta) / cs, sin(theta) / cs])
+            st, ct = rep_sincos(theta) if rep else (sin(theta), cos(theta))
+            rows.append([sx, sy, ct / cs, st / cs])
     return rows
 
 
 def _rk4_kdt(med, X, dt):  # NonObstacle.jl:72-76
     oob = 0
-    H, o = med.hamilton(X); oob |= o
+    if getattr(med, "trig", "libm") == "rep" and hasattr(med, "hamilton_staged"):
+        base, stage = {}, iter(range(4))
+        rhs = lambda Y: med.hamilton_staged(Y, next(stage), base)
+    else:
+        rhs = med.hamilton
+    H, o = rhs(X); oob |= o
     k1 = [h * dt for h in H]
-    H, o = med.hamilton([X[k] + k1[k] / 2 for k in range(4)]); oob |= o
+    H, o = rhs([X[k] + k1[k] / 2 for k in range(4)]); oob |= o
     k2 = [h * dt for h in H]
-    H, o = med.hamilton([X[k] + k2[k] / 2 for k in range(4)]); oob |= o
+    H, o = rhs([X[k] + k2[k] / 2 for k in range(4)]); oob |= o
     k3 = [h * dt for h in H]
-    H, o = med.hamilton([X[k] + k3[k] for k in range(4)]); oob |= o
+    H, o = rhs([X[k] + k3[k] for k in range(4)]); oob |= o
     k4 = [h * dt for h in H]
     return [X[k] + (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]) / 6.0 for k in range(4)], oob
 

@@ -198,6 +198,21 @@ def test_scatter_trefoil_golden(ctx):
     assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
 
 
+def test_scatter_reproducible_trig_golden(ctx):
+    """the committed fixtures of the Python restatement's reproducible sin/cos flavour (exact-rational fma): the
+    analytic smooth demo and the obstacle demo around the trefoil, bit for bit and event for event."""
+    import ray_amd
+    g = golden("scatter_smooth_rep_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelation(ray_amd.SinProd(*g["params"]), None, int(g["ns"]), int(g["nd"]),
+                                      float(g["dt"]), (0.0, math.pi), ctx=ctx, info=True)
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
+    g = golden("scatter_trefoil_rep_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd(*g["params"]), None, ray_amd.Trefoil(*g["trefoil"]),
+                                              None, int(g["ns"]), int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert info["nreflect"].max() >= 2
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
+
+
 def test_scatter_trefoil_vs_oracle(ctx, orc):
     """BASELINE config 3's cavity: ObstacleDemo.jl's sweep (50 x 300, dt = 1e-2, t in steps) around the trefoil
     in the analytic medium, against the oracle's identity flavour (the kernels' own evaluation of the level set).
