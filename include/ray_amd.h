@@ -353,8 +353,19 @@ int ray_group_medium_destroy(ray_group_medium *med);
 int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *med, const ray_obstacle *ob,
                             const ray_shoot_params *prm, double *m_host, int64_t ld,
                             int32_t *status, int32_t *nsteps, int32_t *nreflect);
-/* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit laid them out; columns 5..8 are
- * uploaded once, sharded like m, and stay resident                                                            */
+/* The fixed-time traces of a reconstruction iteration over the members: NonReflectionTrace (Obstacle.jl:275-329,
+ * mode RAY_TRACE_OVERSHOOT) and the trajectory part of ScatterForwardOperator (NonObstacle.jl:141-187, mode
+ * RAY_TRACE_SHORTEN_CEASE), which the reference deals to its workers pid by pid (NonObstacle.jl:236-240).
+ * Arguments as ray_trace_fixed_time; nd = rows per source when m is laid out as ScatterRelation returns it (0: the
+ * library looks for such fans itself).  Fans are dealt to the members as ray_group_shoot_to_exit deals sources
+ * (member k of G: fans k, k + G, ...), rows in any other order in G contiguous blocks.  X_host may be NULL.  Every
+ * member keeps its rows and their traced states resident, so ray_group_set_observation + ray_group_misfit apply
+ * to the traces as they do to a shoot.                                                                          */
+int ray_group_trace_fixed_time(ray_group *g, const ray_group_medium *med, const double *m_host, int64_t num,
+                               int64_t ld, int32_t nd, double dt, int32_t mode, double *X_host, int64_t ldx,
+                               int32_t *status, int32_t *nsteps);
+/* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit / ray_group_trace_fixed_time laid
+ * them out; columns 5..8 are uploaded once, sharded like m, and stay resident                                  */
 int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld);
 /* misfit of the resident slabs of the last shoot against the resident observation; out / mask / mismatch as
  * ray_misfit (mask, mismatch may be NULL); sums to 1e-12 of the single-context ones (order of the all-reduce)  */

@@ -433,6 +433,29 @@ function ScatterRelation(g::RayGroup, c::Matrix{Float64}, ext::Float64, ns::Int,
     m
 end
 
+"NonReflectionTrace (Obstacle.jl:275) over all GPUs of the group; the members keep the traced states for misfit(g)"
+function NonReflectionTrace(g::RayGroup, c::Matrix{Float64}, m, ext::Float64, dt::Float64; nd::Int = 0,
+                            mode::Cint = TRACE_OVERSHOOT)
+    N = size(c, 1)
+    num = size(m, 1)
+    mm = Matrix{Float64}(m)
+    X = Matrix{Float64}(undef, num, 4)
+    med = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_group_medium_create_grid, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), g.h, c, N, ext, med))
+    try
+        check(ccall((:ray_group_trace_fixed_time, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Int32, Cdouble, Int32, Ptr{Cdouble}, Int64,
+                     Ptr{Int32}, Ptr{Int32}),
+                    g.h, med[], mm, num, max(num, 1), nd, dt, mode, X, max(num, 1), C_NULL, C_NULL))
+    finally
+        ccall((:ray_group_medium_destroy, LIB), Cint, (Ptr{Cvoid},), med[])
+    end
+    g.rows = num
+    m[:, 5:8] = X
+    m
+end
+
 "the observation the group's misfit is taken against (rows as the last ScatterRelation(g, ...) laid them out)"
 function set_observation!(g::RayGroup, observation::AbstractMatrix{Float64})
     o = Matrix{Float64}(observation)

@@ -333,6 +333,18 @@ class Group:
             return m, {"status": st, "nsteps": nst, "nreflect": nrf}
         return m
 
+    def trace(self, med, m, dt, mode=TRACE_OVERSHOOT, *, nd=0, info=False):
+        """The fixed-time traces over the group (ray_group_trace_fixed_time): NonReflectionTrace's end states
+        (mode TRACE_OVERSHOOT, Obstacle.jl:275-329) or ScatterForwardOperator's trajectory ends (TRACE_SHORTEN_CEASE,
+        NonObstacle.jl:141-187) for every row of m; the members keep their shares for set_observation + misfit."""
+        m = np.asfortranarray(m, dtype=np.float64)
+        num = m.shape[0]
+        X = np.zeros((num, 4), dtype=np.float64, order="F")
+        st, nst = (np.zeros(num, dtype=np.int32) for _ in range(2))
+        _lib.check(self._lib.ray_group_trace_fixed_time(self.handle, med.handle, _ptr(m), num, max(num, 1), int(nd),
+                                                        float(dt), int(mode), _ptr(X), max(num, 1), _ptr(st), _ptr(nst)))
+        return (X, {"status": st, "nsteps": nst}) if info else X
+
     def set_observation(self, obs):
         obs = np.asfortranarray(obs, dtype=np.float64)
         _lib.check(self._lib.ray_group_set_observation(self.handle, _ptr(obs), obs.shape[0], max(obs.shape[0], 1)))

@@ -23,6 +23,7 @@ struct GroupMember {
     // (rows = count * nd, device ld = max(rows, 1)); in the caller's arrays source i of the share starts at row
     // (first + i * G) * nd
     int64_t rows = 0;
+    int64_t row0 = 0;           // first row of the share in the caller's arrays
     int first = 0, count = 0, nd = 0, G = 1;
     double *d_m = nullptr;      size_t m_cap = 0;
     int32_t *d_int = nullptr;   size_t int_cap = 0;     // status | nsteps | nreflect, rows each
@@ -88,7 +89,7 @@ static void group_sync_all(ray_group *g)
 static hipError_t comb_copy(const GroupMember &m, void *host, void *dev, size_t w, bool to_host)
 {
     if (m.count == 0) return hipSuccess;
-    char *h = static_cast<char *>(host) + (size_t)m.first * (size_t)m.nd * w;
+    char *h = static_cast<char *>(host) + (size_t)m.row0 * w;
     const size_t piece = (size_t)m.nd * w, hpitch = piece * (size_t)m.G;
     return to_host ? hipMemcpy2DAsync(h, hpitch, dev, piece, piece, (size_t)m.count, hipMemcpyDeviceToHost, m.ctx->stream)
                    : hipMemcpy2DAsync(dev, piece, h, hpitch, piece, (size_t)m.count, hipMemcpyHostToDevice, m.ctx->stream);
@@ -269,6 +270,7 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_
     for (int k = 0; k < G; ++k) {
         GroupMember &m = g->mem[(size_t)k];
         m.first = k; m.G = G; m.nd = prm->nd;
+        m.row0 = (int64_t)k * prm->nd;
         m.count = k < nsrc ? (nsrc - k + G - 1) / G : 0;
         m.rows = (int64_t)m.count * prm->nd;
         if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
@@ -303,6 +305,69 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *gm, const ray_
     return RAY_OK;
 }
 
+// ---- the fixed-time traces of a reconstruction iteration over the whole node ---------------------------------------
+// NonReflectionTrace (Obstacle.jl:275-329, mode OVERSHOOT) / the X part of ScatterForwardOperator (NonObstacle.jl:
+// 141-187, mode SHORTEN_CEASE), which the reference hands to its workers pid by pid (NonObstacle.jl:236-240).
+// The rows of m are dealt like ray_group_shoot_to_exit deals them when they are fans (nd rows per source, given or
+// recognised in m): member k of G takes the fans k, k + G, ...; rows in any other order go in G contiguous blocks.
+// Every member keeps its share resident (columns 1-4 and 9 of m, the traced state in columns 5-8), so that
+// ray_group_set_observation + ray_group_misfit apply to the traced states exactly as they do to a shoot.
+int ray_group_trace_fixed_time(ray_group *g, const ray_group_medium *gm, const double *m_host, int64_t num, int64_t ld,
+                               int32_t nd, double dt, int32_t mode, double *X_host, int64_t ldx, int32_t *status,
+                               int32_t *nsteps)
+{
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    if (!gm || gm->g != g) return fail(RAY_ERR_INVALID, "group medium belongs to another group");
+    if (!m_host || num < 0 || ld < num || nd < 0 || (X_host && ldx < num)) return fail(RAY_ERR_INVALID, "bad m / X / num / ld / nd");
+    const int G = (int)g->mem.size();
+    int fan = nd > 0 ? (num % nd == 0 ? nd : 0) : detect_fan(m_host, num, ld);
+    const int64_t nfan = fan ? num / fan : 0, block = (num + G - 1) / G;
+    int rc;
+    for (int k = 0; k < G; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        if (fan) {
+            m.first = k; m.G = G; m.nd = fan; m.row0 = (int64_t)k * fan;
+            m.count = k < nfan ? (int)((nfan - k + G - 1) / G) : 0;
+            m.rows = (int64_t)m.count * fan;
+        } else {
+            m.row0 = std::min<int64_t>((int64_t)k * block, num);
+            m.rows = std::min<int64_t>(block, num - m.row0);
+            if (m.rows > INT32_MAX) { group_sync_all(g); return fail(RAY_ERR_INVALID, "ray_group_trace_fixed_time: more than 2^31 rows per member"); }
+            m.first = k; m.G = 1; m.nd = (int)m.rows; m.count = m.rows ? 1 : 0;
+        }
+        if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
+        const size_t rows1 = (size_t)std::max<int64_t>(m.rows, 1);
+        hipError_t he = grow((void **)&m.d_m, &m.m_cap, rows1 * 9 * sizeof(double));
+        if (he == hipSuccess) he = grow((void **)&m.d_int, &m.int_cap, rows1 * 3 * sizeof(int32_t));
+        if (m.rows == 0 || he != hipSuccess) {
+            if (he != hipSuccess) { group_sync_all(g); return fail(he == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, std::string("ray_group_trace_fixed_time: ") + hipGetErrorString(he)); }
+            continue;
+        }
+        for (int c = 0; c < 9 && he == hipSuccess; ++c)
+            if (c < 4 || c == 8)
+                he = comb_copy(m, const_cast<double *>(m_host) + (size_t)c * (size_t)ld, m.d_m + (size_t)c * (size_t)m.rows, sizeof(double), false);
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_trace_fixed_time: ") + hipGetErrorString(he)); }
+        rc = trace_dev_impl(m.ctx, gm->med[(size_t)k], m.d_m, m.rows, m.rows, dt, mode, m.d_m + 4 * (size_t)m.rows, m.rows,
+                            m.d_int, m.d_int + m.rows, nullptr, nullptr, 0, fan);
+        if (rc) { group_sync_all(g); return rc; }
+    }
+    for (int k = 0; k < G; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        if (m.rows == 0) continue;
+        hipError_t he = hipSetDevice(m.device);
+        for (int c = 0; c < 4 && X_host && he == hipSuccess; ++c)
+            he = comb_copy(m, X_host + (size_t)c * (size_t)ldx, m.d_m + (size_t)(4 + c) * (size_t)m.rows, sizeof(double), true);
+        if (he == hipSuccess && status) he = comb_copy(m, status, m.d_int, sizeof(int32_t), true);
+        if (he == hipSuccess && nsteps) he = comb_copy(m, nsteps, m.d_int + m.rows, sizeof(int32_t), true);
+        if (he != hipSuccess) { group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ray_group_trace_fixed_time: ") + hipGetErrorString(he)); }
+    }
+    for (GroupMember &m : g->mem) {
+        HIPCHK(hipSetDevice(m.device));
+        HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
 // the observation the misfit is taken against (NonObstacle.jl:336 `observation`), sharded like the last shoot
 // and kept resident: the rows of every column go to the member that owns their source
 int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld)
@@ -310,7 +375,7 @@ int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num,
     if (!g || !obs_host) return fail(RAY_ERR_INVALID, "null group / observation");
     int64_t total = 0;
     for (GroupMember &m : g->mem) total += m.rows;
-    if (num != total || ld < num) return fail(RAY_ERR_INVALID, "ray_group_set_observation: num must equal the rows of the last ray_group_shoot_to_exit");
+    if (num != total || ld < num) return fail(RAY_ERR_INVALID, "ray_group_set_observation: num must equal the rows of the last ray_group_shoot_to_exit / ray_group_trace_fixed_time");
     for (GroupMember &m : g->mem) {
         int rc = use(m.ctx);
         if (rc) { group_sync_all(g); return rc; }

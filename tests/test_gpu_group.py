@@ -71,3 +71,43 @@ def test_group_more_members_than_sources_and_obstacle(ctx, orc):
             g.ScatterRelation(ray_amd.Group([0]).sinprod_medium(sp), 2, 8, 1e-2)   # medium of another group
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]], ids=["rccl-1rank", "fold-3"])
+def test_group_trace_reproduces_single_context(ctx, orc, devices):
+    """ray_group_trace_fixed_time: the reconstruction iteration's traces over the members -- fans recognised in m, fans
+    told, rows in no order (contiguous blocks), more members than fans -- equal the single-context traces bit for bit
+    in both modes, and the misfit of the resident traced states against the data equals the single-context one."""
+    import ray_amd
+    ns, nd, N = 7, 60, 45
+    data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, nthreads=4)
+    c0 = np.asfortranarray(0.85 * orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) + 0.1)
+    med1 = ray_amd.GridMedium(c0, 1.5, ctx)
+    perm = np.random.default_rng(3).permutation(ns * nd)
+    shuffled = np.asfortranarray(data[perm])
+    g = ray_amd.Group(devices)
+    try:
+        med = g.grid_medium(c0, 1.5)
+        for mode in (ray_amd.TRACE_SHORTEN_CEASE, ray_amd.TRACE_OVERSHOOT):
+            want, winfo = ray_amd._trace(med1, data, 1.5, 5e-2, mode, ctx, True)
+            for rows, hint in ((data, 0), (data, nd), (data, ns * nd), (shuffled, 0), (data[:nd + 7], 0)):
+                rows = np.asfortranarray(rows)
+                X, info = g.trace(med, rows, 5e-2, mode, nd=hint, info=True)
+                sel = perm if rows is shuffled else np.arange(rows.shape[0])
+                assert np.array_equal(X, want[sel])
+                assert np.array_equal(info["status"], winfo["status"][sel]) and np.array_equal(info["nsteps"], winfo["nsteps"][sel])
+        # the loop's objective: traced states (resident) against the measured data
+        X = g.trace(med, data, 5e-2, ray_amd.TRACE_SHORTEN_CEASE)
+        s = np.array(data, order="F", copy=True)
+        s[:, 4:8] = X
+        ref = ray_amd.misfit(s, data, 0.2, ctx=ctx)
+        g.set_observation(data)
+        got = g.misfit(0.2)
+        assert np.array_equal(got["mismatch"], ref["mismatch"]) and np.array_equal(got["mask"], ref["mask"])
+        assert got["sum_mismatch2"] == pytest.approx(ref["sum_mismatch2"], rel=1e-12)
+        assert got["sum_target2"] == pytest.approx(ref["sum_target2"], rel=1e-12)
+        assert g.trace(med, data[:0], 5e-2).shape == (0, 4)
+        with pytest.raises(ray_amd.RayError):
+            g.trace(g.sinprod_medium(ray_amd.SinProd.smooth_demo()), data, 5e-2)        # gridded media only
+    finally:
+        g.close()
