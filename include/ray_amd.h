@@ -364,6 +364,23 @@ int ray_group_shoot_to_exit(ray_group *g, const ray_group_medium *med, const ray
 int ray_group_trace_fixed_time(ray_group *g, const ray_group_medium *med, const double *m_host, int64_t num,
                                int64_t ld, int32_t nd, double dt, int32_t mode, double *X_host, int64_t ldx,
                                int32_t *status, int32_t *nsteps);
+/* ScatterForwardOperator (NonObstacle.jl:189-243) over the members, as the reference spreads it over its workers
+ * (:236-240): rays dealt as ray_group_trace_fixed_time deals them (nd as there), every member building the block rows
+ * of its rays concurrently (one host thread per member: the operator exchanges step counts with the host half way).
+ * Arguments as ray_forward_operator, without rho.  The result is one ordinary ray_frechet per member:
+ *   ray_group_frechet_member      member k's handle -- every ray_frechet_* pass applies to it -- and its rays: `count`
+ *                                 runs of nd rays, run i = the caller's rays row0 + i*stride .. + nd
+ *   ray_group_frechet_export_csr  the whole M on the host in the caller's row order, i.e. what the reference's master
+ *                                 holds when its workers return (:242); sizes from ray_group_frechet_shape          */
+typedef struct ray_group_frechet ray_group_frechet;
+int ray_group_forward_operator(ray_group *g, ray_group_medium *med, const double *m_host, int64_t num, int64_t ld,
+                               int32_t nd, double dt, double droptol, double *X_host, int64_t ldx, int32_t *status,
+                               int32_t *nsteps, ray_group_frechet **out);
+int ray_group_frechet_shape(ray_group_frechet *f, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+int ray_group_frechet_member(ray_group_frechet *f, int k, ray_frechet **member, int64_t *row0, int32_t *count,
+                             int32_t *nd, int64_t *stride);
+int ray_group_frechet_export_csr(ray_group_frechet *f, int64_t *indptr, int32_t *indices, double *data);
+int ray_group_frechet_destroy(ray_group_frechet *f);
 /* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit / ray_group_trace_fixed_time laid
  * them out; columns 5..8 are uploaded once, sharded like m, and stay resident                                  */
 int ray_group_set_observation(ray_group *g, const double *obs_host, int64_t num, int64_t ld);

@@ -456,6 +456,42 @@ function NonReflectionTrace(g::RayGroup, c::Matrix{Float64}, m, ext::Float64, dt
     m
 end
 
+"ScatterForwardOperator (NonObstacle.jl:189) over all GPUs of the group: (M, s) as the reference's master holds them"
+function ScatterForwardOperator(g::RayGroup, c::Matrix{Float64}, m, ext::Float64, dt::Float64; nd::Int = 0,
+                                droptol::Float64 = 1e-12)
+    num = size(m, 1); N = size(c, 1)
+    mm = Matrix{Float64}(m)
+    X = Matrix{Float64}(undef, num, 4)
+    s = SharedArray{Float64}((num, 9))
+    s[:, 1:4] = m[:, 1:4]; s[:, 9] = m[:, 9]
+    med = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ray_group_medium_create_grid, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), g.h, c, N, ext, med))
+    local M
+    try
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ray_group_forward_operator, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Int32, Cdouble, Cdouble, Ptr{Cdouble}, Int64,
+                     Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                    g.h, med[], mm, num, max(num, 1), nd, dt, droptol, X, max(num, 1), C_NULL, C_NULL, h))
+        try
+            nr = Ref{Int64}(0); nc = Ref{Int64}(0); nz = Ref{Int64}(0)
+            check(ccall((:ray_group_frechet_shape, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), h[], nr, nc, nz))
+            indptr = Vector{Int64}(undef, nr[] + 1); indices = Vector{Int32}(undef, nz[]); data = Vector{Float64}(undef, nz[])
+            check(ccall((:ray_group_frechet_export_csr, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Cdouble}),
+                        h[], indptr, indices, data))
+            Mt = SparseMatrixCSC(Int(nc[]), Int(nr[]), indptr .+ 1, Int64.(indices) .+ 1, data)   # = M'
+            M = copy(transpose(Mt))
+        finally
+            ccall((:ray_group_frechet_destroy, LIB), Cint, (Ptr{Cvoid},), h[])
+        end
+    finally
+        ccall((:ray_group_medium_destroy, LIB), Cint, (Ptr{Cvoid},), med[])
+    end
+    s[:, 5:8] = X
+    M, s
+end
+
 "the observation the group's misfit is taken against (rows as the last ScatterRelation(g, ...) laid them out)"
 function set_observation!(g::RayGroup, observation::AbstractMatrix{Float64})
     o = Matrix{Float64}(observation)

@@ -345,6 +345,22 @@ class Group:
                                                         float(dt), int(mode), _ptr(X), max(num, 1), _ptr(st), _ptr(nst)))
         return (X, {"status": st, "nsteps": nst}) if info else X
 
+    def ScatterForwardOperator(self, med, m, dt, *, nd=0, droptol=1e-12, info=False):
+        """ScatterForwardOperator (NonObstacle.jl:189-243) over the group: returns (M, s) with M a GroupFrechetMatrix
+        (one device-resident part per member; `.tocsr()` is the whole matrix in m's row order) and s = m with columns
+        5..8 replaced by the traced states (:196, :185)."""
+        m = np.asfortranarray(m, dtype=np.float64)
+        num = m.shape[0]
+        X = np.zeros((num, 4), dtype=np.float64, order="F")
+        st, nst = (np.zeros(num, dtype=np.int32) for _ in range(2))
+        h = C.c_void_p()
+        _lib.check(self._lib.ray_group_forward_operator(self.handle, med.handle, _ptr(m), num, max(num, 1), int(nd), float(dt),
+                                                        float(droptol), _ptr(X), max(num, 1), _ptr(st), _ptr(nst), C.byref(h)))
+        s = np.array(m, order="F", copy=True)
+        s[:, 4:8] = X
+        M = GroupFrechetMatrix(self, h)
+        return (M, s, {"status": st, "nsteps": nst}) if info else (M, s)
+
     def set_observation(self, obs):
         obs = np.asfortranarray(obs, dtype=np.float64)
         _lib.check(self._lib.ray_group_set_observation(self.handle, _ptr(obs), obs.shape[0], max(obs.shape[0], 1)))
@@ -528,12 +544,54 @@ def _trace(c, m, ext, dt, mode, ctx, info, nd=0):
     return X, {"status": st, "nsteps": nst}
 
 
+class GroupFrechetMatrix:
+    """The Frechet matrix of Group.ScatterForwardOperator (ray_group_frechet): member k holds the rows of its rays as an
+    ordinary FrechetMatrix (`members()`), `.tocsr()` assembles the whole matrix on the host in the caller's row order."""
+
+    def __init__(self, group, handle):
+        self.group, self.handle = group, handle
+        r, c, n = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(group._lib.ray_group_frechet_shape(handle, C.byref(r), C.byref(c), C.byref(n)))
+        self.shape, self.nnz = (r.value, c.value), n.value
+
+    def tocsr(self):
+        import scipy.sparse as sps
+        indptr = np.zeros(self.shape[0] + 1, dtype=np.int64)
+        indices = np.zeros(self.nnz, dtype=np.int32)
+        data = np.zeros(self.nnz, dtype=np.float64)
+        _lib.check(self.group._lib.ray_group_frechet_export_csr(self.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
+        return sps.csr_matrix((data, indices, indptr), shape=self.shape)
+
+    def members(self):
+        """[(FrechetMatrix, rays)]: member k's part (not owned: it lives as long as this object) and the caller's ray
+        indices its local rays 0, 1, ... stand for."""
+        out = []
+        for k in range(self.group.size):
+            f, row0, cnt, nd, stride = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64()
+            _lib.check(self.group._lib.ray_group_frechet_member(self.handle, k, C.byref(f), C.byref(row0), C.byref(cnt),
+                                                                C.byref(nd), C.byref(stride)))
+            rays = (row0.value + stride.value * np.arange(cnt.value)[:, None] + np.arange(nd.value)[None, :]).reshape(-1)
+            out.append((FrechetMatrix(self.group, f, owned=False), rays))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.group._lib.ray_group_frechet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FrechetMatrix:
     """Device-resident CSR form of the Frechet matrix M (ray_frechet handle): rows 4*ray + component,
     columns i + j*N.  `.tocsr()` copies it to a scipy.sparse.csr_matrix."""
 
-    def __init__(self, ctx, handle):
-        self.ctx, self.handle = ctx, handle
+    def __init__(self, ctx, handle, owned=True):
+        self.ctx, self.handle, self.owned = ctx, handle, owned
         r, c, n = C.c_int64(), C.c_int64(), C.c_int64()
         _lib.check(ctx._lib.ray_frechet_shape(handle, C.byref(r), C.byref(c), C.byref(n)))
         self.shape, self.nnz = (r.value, c.value), n.value
@@ -616,9 +674,9 @@ class FrechetMatrix:
         return fid, res
 
     def close(self):
-        if self.handle:
+        if self.handle and self.owned:
             self.ctx._lib.ray_frechet_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

@@ -102,6 +102,12 @@ SIGNATURES = {
     "ray_group_medium_destroy": [_vp],
     "ray_group_shoot_to_exit": [_vp, _vp, C.POINTER(Obstacle), C.POINTER(ShootParams), _vp, _i64, _vp, _vp, _vp],
     "ray_group_trace_fixed_time": [_vp, _vp, _vp, _i64, _i64, C.c_int32, _f64, C.c_int32, _vp, _i64, _vp, _vp],
+    "ray_group_forward_operator": [_vp, _vp, _vp, _i64, _i64, C.c_int32, _f64, _f64, _vp, _i64, _vp, _vp, C.POINTER(_vp)],
+    "ray_group_frechet_shape": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "ray_group_frechet_member": [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                 C.POINTER(_i64)],
+    "ray_group_frechet_export_csr": [_vp, _vp, _vp, _vp],
+    "ray_group_frechet_destroy": [_vp],
     "ray_group_set_observation": [_vp, _vp, _i64, _i64],
     "ray_group_misfit": [_vp, _vp, _vp, _f64, _vp],
     "ray_group_get_counters": [_vp, C.POINTER(Counters)],

@@ -15,6 +15,7 @@
 // order -- same device memory, no collective needed.
 #pragma once
 #include <rccl/rccl.h>
+#include <thread>
 
 struct GroupMember {
     ray_ctx *ctx = nullptr;
@@ -41,6 +42,16 @@ struct ray_group {
     std::vector<ncclComm_t> comms;
     const double **d_ptrs = nullptr;                    // fold path: the members' d_sums, on device mem[0].device
     std::vector<ray_group_medium *> media;
+};
+
+// the Frechet matrix of one ray_group_forward_operator: one ordinary ray_frechet per member over its share of the rays
+struct GroupShare { int64_t row0 = 0, rows = 0; int count = 0, nd = 0, G = 1; };
+struct ray_group_frechet {
+    ray_group *g = nullptr;
+    std::vector<ray_frechet *> f;
+    std::vector<GroupShare> share;
+    int64_t num = 0;
+    int N = 0;
 };
 
 struct ray_group_medium {
@@ -364,6 +375,164 @@ int ray_group_trace_fixed_time(ray_group *g, const ray_group_medium *gm, const d
     for (GroupMember &m : g->mem) {
         HIPCHK(hipSetDevice(m.device));
         HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
+// ---- ScatterForwardOperator over the whole node (NonObstacle.jl:189-243; its workers: :236-240) ------------------------
+// Rays are dealt as ray_group_trace_fixed_time deals them.  ray_forward_operator talks to the host in the middle of
+// its work (step counts come back for the grouping of rays into waves), so every member runs on a host thread of its
+// own; each works from a packed copy of its rows and returns an ordinary ray_frechet over them.
+static void group_share_rows(const GroupShare &sh, int64_t r, int64_t *global_first, int64_t *run)
+{
+    const int64_t p = r / sh.nd;                       // piece (fan) of the share that local ray r starts
+    *global_first = sh.row0 + p * (int64_t)sh.G * sh.nd + (r - p * sh.nd);
+    *run = sh.nd - (r - p * sh.nd);
+}
+
+int ray_group_frechet_destroy(ray_group_frechet *gf)
+{
+    if (!gf) return RAY_OK;
+    int rc = RAY_OK;
+    for (ray_frechet *f : gf->f)
+        if (f) { const int r = ray_frechet_destroy(f); if (r) rc = r; }
+    delete gf;
+    return rc;
+}
+
+int ray_group_forward_operator(ray_group *g, ray_group_medium *gm, const double *m_host, int64_t num, int64_t ld,
+                               int32_t nd, double dt, double droptol, double *X_host, int64_t ldx, int32_t *status,
+                               int32_t *nsteps, ray_group_frechet **out)
+{
+    if (!out) return fail(RAY_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!g) return fail(RAY_ERR_INVALID, "null group");
+    if (!gm || gm->g != g) return fail(RAY_ERR_INVALID, "group medium belongs to another group");
+    if (!m_host || !X_host || num < 0 || ld < num || ldx < num || nd < 0) return fail(RAY_ERR_INVALID, "bad m / X / num / ld / nd");
+    const int G = (int)g->mem.size();
+    const int fan = nd > 0 ? (num % nd == 0 ? nd : 0) : detect_fan(m_host, num, ld);
+    const int64_t nfan = fan ? num / fan : 0, block = (num + G - 1) / G;
+    ray_group_frechet *gf = new ray_group_frechet;
+    gf->g = g; gf->num = num; gf->N = gm->med.empty() ? 0 : gm->med[0]->N;
+    gf->f.assign((size_t)G, nullptr);
+    gf->share.resize((size_t)G);
+    for (int k = 0; k < G; ++k) {
+        GroupShare &sh = gf->share[(size_t)k];
+        if (fan) {
+            sh.G = G; sh.nd = fan; sh.row0 = (int64_t)k * fan;
+            sh.count = k < nfan ? (int)((nfan - k + G - 1) / G) : 0;
+            sh.rows = (int64_t)sh.count * fan;
+        } else {
+            sh.row0 = std::min<int64_t>((int64_t)k * block, num);
+            sh.rows = std::min<int64_t>(block, num - sh.row0);
+            sh.G = 1; sh.nd = (int)std::max<int64_t>(sh.rows, 1); sh.count = sh.rows ? 1 : 0;
+        }
+    }
+    std::vector<int> rcs((size_t)G, RAY_OK);
+    std::vector<std::string> errs((size_t)G);
+    auto work = [&](int k) {
+        const GroupShare &sh = gf->share[(size_t)k];
+        const int64_t n = sh.rows, ldk = std::max<int64_t>(n, 1);
+        std::vector<double> mk((size_t)ldk * 9), Xk((size_t)ldk * 4);
+        std::vector<int32_t> stk((size_t)ldk), nsk((size_t)ldk);
+        for (int p = 0; p < sh.count; ++p) {
+            const int64_t src = sh.row0 + (int64_t)p * sh.G * sh.nd, dst = (int64_t)p * sh.nd;
+            for (int c = 0; c < 9; ++c)
+                if (c < 4 || c == 8) std::memcpy(&mk[(size_t)(dst + c * ldk)], m_host + src + (int64_t)c * ld, sizeof(double) * (size_t)sh.nd);
+        }
+        rcs[(size_t)k] = ray_forward_operator(g->mem[(size_t)k].ctx, gm->med[(size_t)k], mk.data(), n, ldk, dt, droptol,
+                                               Xk.data(), ldk, nullptr, stk.data(), nsk.data(), &gf->f[(size_t)k]);
+        if (rcs[(size_t)k]) { errs[(size_t)k] = ray_last_error(); return; }
+        for (int p = 0; p < sh.count; ++p) {
+            const int64_t dst = sh.row0 + (int64_t)p * sh.G * sh.nd, src = (int64_t)p * sh.nd;
+            for (int c = 0; c < 4; ++c) std::memcpy(X_host + dst + (int64_t)c * ldx, &Xk[(size_t)(src + c * ldk)], sizeof(double) * (size_t)sh.nd);
+            if (status) std::memcpy(status + dst, &stk[(size_t)src], sizeof(int32_t) * (size_t)sh.nd);
+            if (nsteps) std::memcpy(nsteps + dst, &nsk[(size_t)src], sizeof(int32_t) * (size_t)sh.nd);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < G; ++k) th.emplace_back(work, k);
+    work(0);
+    for (std::thread &t : th) t.join();
+    for (int k = 0; k < G; ++k)
+        if (rcs[(size_t)k]) {
+            const int rc = rcs[(size_t)k];
+            const std::string msg = "ray_group_forward_operator (member " + std::to_string(k) + "): " + errs[(size_t)k];
+            ray_group_frechet_destroy(gf);
+            return fail(rc, msg);
+        }
+    *out = gf;
+    return RAY_OK;
+}
+
+int ray_group_frechet_shape(ray_group_frechet *gf, int64_t *n_rows, int64_t *n_cols, int64_t *nnz)
+{
+    if (!gf) return fail(RAY_ERR_INVALID, "null handle");
+    if (n_rows) *n_rows = 4 * gf->num;
+    if (n_cols) *n_cols = (int64_t)gf->N * gf->N;
+    if (nnz) {
+        *nnz = 0;
+        for (ray_frechet *f : gf->f) *nnz += f ? f->nnz : 0;
+    }
+    return RAY_OK;
+}
+
+// member k's part: an ordinary handle (every ray_frechet_* pass applies to it) over `count` runs of nd rays, run i being
+// the caller's rays row0 + i * stride .. + nd
+int ray_group_frechet_member(ray_group_frechet *gf, int k, ray_frechet **f, int64_t *row0, int32_t *count, int32_t *nd,
+                             int64_t *stride)
+{
+    if (!gf || k < 0 || k >= (int)gf->f.size()) return fail(RAY_ERR_INVALID, "bad handle / member");
+    const GroupShare &sh = gf->share[(size_t)k];
+    if (f) *f = gf->f[(size_t)k];
+    if (row0) *row0 = sh.row0;
+    if (count) *count = sh.count;
+    if (nd) *nd = sh.nd;
+    if (stride) *stride = (int64_t)sh.G * sh.nd;
+    return RAY_OK;
+}
+
+// the whole M = droptol!(sparse(M), 1e-12) (NonObstacle.jl:242) on the host, rows in the caller's order: what the
+// reference's master holds after its workers return
+int ray_group_frechet_export_csr(ray_group_frechet *gf, int64_t *indptr, int32_t *indices, double *data)
+{
+    if (!gf || !indptr) return fail(RAY_ERR_INVALID, "null argument");
+    int64_t total = 0;
+    for (ray_frechet *f : gf->f) total += f ? f->nnz : 0;
+    if (total && (!indices || !data)) return fail(RAY_ERR_INVALID, "null indices / data");
+    const size_t G = gf->f.size();
+    std::vector<std::vector<int64_t>> ip(G);
+    std::vector<std::vector<int32_t>> ix(G);
+    std::vector<std::vector<double>> dv(G);
+    indptr[0] = 0;
+    for (size_t k = 0; k < G; ++k) {                    // row lengths into indptr[row + 1]
+        ray_frechet *f = gf->f[k];
+        const GroupShare &sh = gf->share[k];
+        if (!f || sh.rows == 0) continue;
+        ip[k].resize((size_t)(4 * sh.rows + 1));
+        ix[k].resize((size_t)std::max<int64_t>(f->nnz, 1));
+        dv[k].resize((size_t)std::max<int64_t>(f->nnz, 1));
+        const int rc = ray_frechet_export_csr(f, ip[k].data(), ix[k].data(), dv[k].data());
+        if (rc) return rc;
+        for (int64_t r = 0; r < sh.rows; r += sh.nd) {
+            int64_t g0, run;
+            group_share_rows(sh, r, &g0, &run);
+            for (int64_t q = 0; q < 4 * (int64_t)sh.nd; ++q) indptr[4 * g0 + q + 1] = ip[k][(size_t)(4 * r + q + 1)] - ip[k][(size_t)(4 * r + q)];
+        }
+    }
+    for (int64_t q = 0; q < 4 * gf->num; ++q) indptr[q + 1] += indptr[q];
+    for (size_t k = 0; k < G; ++k) {
+        const GroupShare &sh = gf->share[k];
+        if (ip[k].empty()) continue;
+        for (int64_t r = 0; r < sh.rows; r += sh.nd) {
+            int64_t g0, run;
+            group_share_rows(sh, r, &g0, &run);
+            const int64_t a = ip[k][(size_t)(4 * r)], b = ip[k][(size_t)(4 * (r + sh.nd))];
+            if (b > a) {
+                std::memcpy(indices + indptr[4 * g0], &ix[k][(size_t)a], sizeof(int32_t) * (size_t)(b - a));
+                std::memcpy(data + indptr[4 * g0], &dv[k][(size_t)a], sizeof(double) * (size_t)(b - a));
+            }
+        }
     }
     return RAY_OK;
 }

@@ -111,3 +111,39 @@ def test_group_trace_reproduces_single_context(ctx, orc, devices):
             g.trace(g.sinprod_medium(ray_amd.SinProd.smooth_demo()), data, 5e-2)        # gridded media only
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]], ids=["one-member", "three-members"])
+def test_group_forward_operator_reproduces_single_context(ctx, orc, devices):
+    """ray_group_forward_operator: (M, s) of ScatterForwardOperator built by the members concurrently equals the
+    single-context one -- s bit for bit, M entry for entry (same kernels on the same rays) -- for fans, shuffled rows
+    and ragged counts; the members' parts are ordinary handles (dofs on them = the single-context dofs of their rays)."""
+    import ray_amd
+    ns, nd, N = 5, 48, 33
+    data, _, _, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2, nthreads=4)
+    c0 = np.asfortranarray(0.85 * orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.5) + 0.1)
+    med1 = ray_amd.GridMedium(c0, 1.5, ctx)
+    perm = np.random.default_rng(4).permutation(ns * nd)
+    g = ray_amd.Group(devices)
+    try:
+        med = g.grid_medium(c0, 1.5)
+        for rows in (data, np.asfortranarray(data[perm]), np.asfortranarray(data[:nd + 5])):
+            M1, s1 = ray_amd.ScatterForwardOperator(med1, rows, 1.5, 5e-2, ctx=ctx)
+            M, s, info = g.ScatterForwardOperator(med, rows, 5e-2, info=True)
+            assert np.array_equal(s, s1)
+            A, A1 = M.tocsr(), M1
+            assert A.shape == A1.shape and A.nnz == A1.nnz
+            assert np.array_equal(A.indptr, A1.indptr) and np.array_equal(A.indices, A1.indices)
+            assert np.array_equal(A.data, A1.data)
+            fid = np.linspace(0.0, 1.0, N * N)
+            Md = ray_amd.forward_operator_dev(med1, rows, 1.5, 5e-2, ctx=ctx, want_rho=False)[0]
+            want = Md.dofs(fid)
+            for part, rays in M.members():
+                assert np.allclose(part.dofs(fid), want[rays], rtol=0, atol=1e-12)
+            M.close()
+        M, s = g.ScatterForwardOperator(med, data[:0], 5e-2)
+        assert M.shape == (0, N * N) and M.nnz == 0 and s.shape == (0, 9)
+        with pytest.raises(ray_amd.RayError):
+            g.ScatterForwardOperator(g.sinprod_medium(ray_amd.SinProd.smooth_demo()), data, 5e-2)
+    finally:
+        g.close()

@@ -107,7 +107,8 @@ def test_shim_covers_the_boundary():
                 "ray_frechet_export_csr", "ray_frechet_dofs", "ray_frechet_matvec", "ray_frechet_matvec_t",
                 "ray_frechet_normal_matvec", "ray_frechet_normal_diag", "ray_frechet_fidelity_update", "ray_classify",
                 "ray_misfit", "ray_medium_create_grid", "ray_medium_create_sinprod", "ray_medium_create_radial",
-                "ray_group_create", "ray_group_shoot_to_exit", "ray_group_trace_fixed_time", "ray_group_set_observation",
+                "ray_group_create", "ray_group_shoot_to_exit", "ray_group_trace_fixed_time", "ray_group_forward_operator",
+                "ray_group_frechet_export_csr", "ray_group_set_observation",
                 "ray_group_misfit",
                 "ray_ctx_set_arith"):
         assert sym in used, sym
