@@ -380,6 +380,13 @@ int ray_group_frechet_shape(ray_group_frechet *f, int64_t *n_rows, int64_t *n_co
 int ray_group_frechet_member(ray_group_frechet *f, int k, ray_frechet **member, int64_t *row0, int32_t *count,
                              int32_t *nd, int64_t *stride);
 int ray_group_frechet_export_csr(ray_group_frechet *f, int64_t *indptr, int32_t *indices, double *data);
+/* The two passes of the loop that end in a sum over all rays, with ONE all-reduce of N^2 doubles over the members
+ * (RCCL; members sharing a device: a fold kernel in member order) -- the gradient sums of the sharded loop:
+ *   matvec_t         b = M[order,:]' * v[order]                  (NonObstacle.jl:354; v: 4 num, ray-major)
+ *   normal_matvec    w = M[order,:]' * (M[order,:] * x)          (the action of :353's MtM; x: N^2)
+ * v / ray_mask are host arrays in the caller's row order (ray_mask: num entries or NULL = all), b / w host, N^2. */
+int ray_group_frechet_matvec_t(ray_group_frechet *f, const double *v, const uint8_t *ray_mask, double *b);
+int ray_group_frechet_normal_matvec(ray_group_frechet *f, const double *x, const uint8_t *ray_mask, double *w);
 int ray_group_frechet_destroy(ray_group_frechet *f);
 /* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit / ray_group_trace_fixed_time laid
  * them out; columns 5..8 are uploaded once, sharded like m, and stay resident                                  */

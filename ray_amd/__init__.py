@@ -562,6 +562,27 @@ class GroupFrechetMatrix:
         _lib.check(self.group._lib.ray_group_frechet_export_csr(self.handle, _ptr(indptr), _ptr(indices), _ptr(data)))
         return sps.csr_matrix((data, indices, indptr), shape=self.shape)
 
+    def _reduce(self, fn, vec, n, ray_mask):
+        vec = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1)
+        if vec.size != n:
+            raise ValueError(f"expected a vector of length {n}, got {vec.size}")
+        mk = None
+        if ray_mask is not None:
+            mk = np.ascontiguousarray(ray_mask, dtype=np.uint8).reshape(-1)
+            if mk.size != self.shape[0] // 4:
+                raise ValueError("ray_mask must have one entry per ray")
+        out = np.zeros(self.shape[1])
+        _lib.check(fn(self.handle, _ptr(vec), _ptr(mk) if mk is not None else None, _ptr(out)))
+        return out
+
+    def matvec_t(self, v, ray_mask=None):
+        """b = M[order,:]' v[order] summed over the members with one all-reduce (NonObstacle.jl:354)."""
+        return self._reduce(self.group._lib.ray_group_frechet_matvec_t, v, self.shape[0], ray_mask)
+
+    def normal_matvec(self, x, ray_mask=None):
+        """w = M[order,:]' (M[order,:] x) summed over the members with one all-reduce (the action of :353's MtM)."""
+        return self._reduce(self.group._lib.ray_group_frechet_normal_matvec, x, self.shape[1], ray_mask)
+
     def members(self):
         """[(FrechetMatrix, rays)]: member k's part (not owned: it lives as long as this object) and the caller's ray
         indices its local rays 0, 1, ... stand for."""

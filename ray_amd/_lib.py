@@ -107,6 +107,8 @@ SIGNATURES = {
     "ray_group_frechet_member": [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(_i64)],
     "ray_group_frechet_export_csr": [_vp, _vp, _vp, _vp],
+    "ray_group_frechet_matvec_t": [_vp, _vp, _vp, _vp],
+    "ray_group_frechet_normal_matvec": [_vp, _vp, _vp, _vp],
     "ray_group_frechet_destroy": [_vp],
     "ray_group_set_observation": [_vp, _vp, _i64, _i64],
     "ray_group_misfit": [_vp, _vp, _vp, _f64, _vp],

@@ -33,6 +33,10 @@ struct GroupMember {
     uint8_t *d_mask = nullptr;  size_t mask_cap = 0;
     double *d_mis = nullptr;    size_t mis_cap = 0;
     double *d_sums = nullptr;                           // [0..2) own sums, [2..4) reduced
+    // the group's passes over M: this member's input vector (4 per ray, or N^2), ray mask and N^2 result
+    double *d_gv = nullptr;     size_t gv_cap = 0;
+    uint8_t *d_gmask = nullptr; size_t gmask_cap = 0;
+    double *d_gb = nullptr;     size_t gb_cap = 0;
     hipEvent_t done = nullptr;
 };
 
@@ -41,6 +45,7 @@ struct ray_group {
     bool use_rccl = false;
     std::vector<ncclComm_t> comms;
     const double **d_ptrs = nullptr;                    // fold path: the members' d_sums, on device mem[0].device
+    const double **d_bptrs = nullptr;                   // fold path: the members' d_gb
     std::vector<ray_group_medium *> media;
 };
 
@@ -68,6 +73,16 @@ __global__ void k_group_fold(const double *const *parts, int n, double *out)
         for (int k = 1; k < n; ++k) s = s + parts[k][threadIdx.x];
         out[threadIdx.x] = s;
     }
+}
+
+// fold path for the N^2-long results: out[i] = sum over members of parts[k][i], in member order
+__global__ void k_group_fold_vec(const double *const *parts, int n, int64_t len, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double s = parts[0][i];
+    for (int k = 1; k < n; ++k) s = s + parts[k][i];
+    out[i] = s;
 }
 
 static hipError_t grow(void **p, size_t *cap, size_t bytes)
@@ -126,10 +141,14 @@ int ray_group_destroy(ray_group *g)
         if (m.d_mask) (void)hipFree(m.d_mask);
         if (m.d_mis) (void)hipFree(m.d_mis);
         if (m.d_sums) (void)hipFree(m.d_sums);
+        if (m.d_gv) (void)hipFree(m.d_gv);
+        if (m.d_gmask) (void)hipFree(m.d_gmask);
+        if (m.d_gb) (void)hipFree(m.d_gb);
         if (m.done) (void)hipEventDestroy(m.done);
         if (m.ctx) ray_ctx_destroy(m.ctx);
     }
     if (g->d_ptrs) { (void)hipSetDevice(g->mem[0].device); (void)hipFree(g->d_ptrs); }
+    if (g->d_bptrs) { (void)hipSetDevice(g->mem[0].device); (void)hipFree(g->d_bptrs); }
     delete g;
     return RAY_OK;
 }
@@ -535,6 +554,89 @@ int ray_group_frechet_export_csr(ray_group_frechet *gf, int64_t *indptr, int32_t
         }
     }
     return RAY_OK;
+}
+
+// ---- the passes of the loop that end in a sum over all rays: ONE all-reduce of N^2 doubles -------------------------------
+// b = M[order,:]' * v[order] (the gradient of NonObstacle.jl:354, `normal` = 0) and w = M[order,:]' * (M[order,:] * x)
+// (the action of :353's MtM, `normal` = 1): every member runs the pass over its rays into its own N^2 vector, the
+// vectors are summed across the members (ncclAllReduce over RCCL; members on one device: a fold kernel, member order),
+// and the caller gets the sum.  in: v (4 num, ray-major, caller's row order) or x (N^2); ray_mask: num or NULL.
+static int group_frechet_reduce(ray_group_frechet *gf, const double *in, const uint8_t *ray_mask, double *out_host, int normal)
+{
+    if (!gf || !in || !out_host) return fail(RAY_ERR_INVALID, "null argument");
+    ray_group *g = gf->g;
+    const int G = (int)g->mem.size();
+    const size_t nn = (size_t)gf->N * (size_t)gf->N;
+    int rc;
+    std::vector<double> vk;
+    std::vector<uint8_t> mk;
+    for (int k = 0; k < G; ++k) {
+        GroupMember &m = g->mem[(size_t)k];
+        const GroupShare &sh = gf->share[(size_t)k];
+        if ((rc = use(m.ctx))) { group_sync_all(g); return rc; }
+        const size_t rows1 = (size_t)std::max<int64_t>(sh.rows, 1);
+        hipError_t he = grow((void **)&m.d_gv, &m.gv_cap, sizeof(double) * (normal ? nn : 4 * rows1));
+        if (he == hipSuccess) he = grow((void **)&m.d_gmask, &m.gmask_cap, rows1);
+        if (he == hipSuccess) he = grow((void **)&m.d_gb, &m.gb_cap, sizeof(double) * nn);
+        if (he == hipSuccess && normal) he = hipMemcpyAsync(m.d_gv, in, sizeof(double) * nn, hipMemcpyHostToDevice, m.ctx->stream);
+        if (he == hipSuccess && (!normal || ray_mask) && sh.rows) {
+            // the member's rays out of the caller's order (pageable staging: synchronous before the vectors are reused)
+            if (!normal) vk.resize(4 * (size_t)sh.rows);
+            if (ray_mask) mk.resize((size_t)sh.rows);
+            for (int p = 0; p < sh.count; ++p) {
+                const int64_t src = sh.row0 + (int64_t)p * sh.G * sh.nd, dst = (int64_t)p * sh.nd;
+                if (!normal) std::memcpy(&vk[4 * (size_t)dst], in + 4 * src, sizeof(double) * 4 * (size_t)sh.nd);
+                if (ray_mask) std::memcpy(&mk[(size_t)dst], ray_mask + src, (size_t)sh.nd);
+            }
+            if (!normal) he = hipMemcpy(m.d_gv, vk.data(), sizeof(double) * 4 * (size_t)sh.rows, hipMemcpyHostToDevice);
+            if (he == hipSuccess && ray_mask) he = hipMemcpy(m.d_gmask, mk.data(), (size_t)sh.rows, hipMemcpyHostToDevice);
+        }
+        if (he != hipSuccess) { group_sync_all(g); return fail(he == hipErrorOutOfMemory ? RAY_ERR_NOMEM : RAY_ERR_HIP, std::string("ray_group_frechet pass: ") + hipGetErrorString(he)); }
+        ray_frechet *f = gf->f[(size_t)k];
+        rc = normal ? ray_frechet_normal_matvec_dev(f, m.d_gv, ray_mask ? m.d_gmask : nullptr, m.d_gb)
+                    : ray_frechet_matvec_t_dev(f, m.d_gv, ray_mask ? m.d_gmask : nullptr, m.d_gb);
+        if (rc) { group_sync_all(g); return rc; }
+    }
+    GroupMember &m0 = g->mem[0];
+    if (g->use_rccl) {
+        NCCLCHK(ncclGroupStart());
+        for (int k = 0; k < G; ++k) {
+            GroupMember &m = g->mem[(size_t)k];
+            ncclResult_t r = ncclAllReduce(m.d_gb, m.d_gb, nn, ncclDouble, ncclSum, g->comms[(size_t)k], m.ctx->stream);
+            if (r != ncclSuccess) { (void)ncclGroupEnd(); group_sync_all(g); return fail(RAY_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+        }
+        NCCLCHK(ncclGroupEnd());
+    } else if (G > 1) {
+        HIPCHK(hipSetDevice(m0.device));
+        std::vector<const double *> ptrs((size_t)G);
+        for (int k = 0; k < G; ++k) ptrs[(size_t)k] = g->mem[(size_t)k].d_gb;
+        if (!g->d_bptrs) HIPCHK(hipMalloc((void **)&g->d_bptrs, sizeof(double *) * (size_t)G));
+        HIPCHK(hipMemcpy(g->d_bptrs, ptrs.data(), sizeof(double *) * (size_t)G, hipMemcpyHostToDevice));
+        for (int k = 1; k < G; ++k) {
+            HIPCHK(hipEventRecord(g->mem[(size_t)k].done, g->mem[(size_t)k].ctx->stream));
+            HIPCHK(hipStreamWaitEvent(m0.ctx->stream, g->mem[(size_t)k].done, 0));
+        }
+        // member 0's own vector is both a part and the result: each element is read (all parts) before it is written
+        hipLaunchKernelGGL(k_group_fold_vec, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, m0.ctx->stream, g->d_bptrs, G, (int64_t)nn, m0.d_gb);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipSetDevice(m0.device));
+    HIPCHK(hipMemcpyAsync(out_host, m0.d_gb, sizeof(double) * nn, hipMemcpyDeviceToHost, m0.ctx->stream));
+    for (GroupMember &m : g->mem) {
+        HIPCHK(hipSetDevice(m.device));
+        HIPCHK(hipStreamSynchronize(m.ctx->stream));
+    }
+    return RAY_OK;
+}
+
+int ray_group_frechet_matvec_t(ray_group_frechet *gf, const double *v, const uint8_t *ray_mask, double *b)
+{
+    return group_frechet_reduce(gf, v, ray_mask, b, 0);
+}
+
+int ray_group_frechet_normal_matvec(ray_group_frechet *gf, const double *x, const uint8_t *ray_mask, double *w)
+{
+    return group_frechet_reduce(gf, x, ray_mask, w, 1);
 }
 
 // the observation the misfit is taken against (NonObstacle.jl:336 `observation`), sharded like the last shoot

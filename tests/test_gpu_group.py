@@ -140,6 +140,17 @@ def test_group_forward_operator_reproduces_single_context(ctx, orc, devices):
             want = Md.dofs(fid)
             for part, rays in M.members():
                 assert np.allclose(part.dofs(fid), want[rays], rtol=0, atol=1e-12)
+            # the gradient sums: one all-reduce of N^2 doubles over the members (fp64 atomics: order-dependent rounding)
+            rng = np.random.default_rng(8)
+            v, x = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[1])
+            mask = (rng.random(A.shape[0] // 4) < 0.7).astype(np.uint8)
+            sel = np.repeat(mask.astype(bool), 4)
+            for mk, rows_sel in ((None, slice(None)), (mask, sel)):
+                b, w = M.matvec_t(v, mk), M.normal_matvec(x, mk)
+                b_ref = A1[rows_sel].T @ v[rows_sel]
+                w_ref = A1[rows_sel].T @ (A1[rows_sel] @ x)
+                assert np.max(np.abs(b - b_ref)) <= 1e-12 * max(1.0, np.max(np.abs(b_ref)))
+                assert np.max(np.abs(w - w_ref)) <= 1e-12 * max(1.0, np.max(np.abs(w_ref)))
             M.close()
         M, s = g.ScatterForwardOperator(med, data[:0], 5e-2)
         assert M.shape == (0, N * N) and M.nnz == 0 and s.shape == (0, 9)
