@@ -486,6 +486,22 @@ def test_misfit_vs_oracle(ctx, orc, num):
 
 
 # ---- size-independent properties at the BASELINE config-2 size (2048 x 2048 rays, 512^2 grid) --------
+@pytest.mark.parametrize("shape", ["circle", "trefoil"])
+def test_full_size_analytic_obstacle_every_ray(ctx, orc, shape):
+    """BASELINE config 3 at the timing size: ObstacleDemo's analytic medium around the circle and around
+    the trefoil with its cavities, 2048 x 2048 rays, dt = 1e-2, t in steps -- EVERY ray against the oracle's
+    reproducible-sin/cos (and identity) flavour, bit for bit and event for event (0.84 / 2.0 million reflections;
+    ~6 s of CPU on the box's 16 threads each), the whole call from (ns, nd)."""
+    import ray_amd
+    ns, nd, dt = 2048, 2048, 1e-2
+    ob, orc_ob = (ray_amd.Circle(0.3), 0.3) if shape == "circle" else (ray_amd.Trefoil.demo(), ("trefoil", 0.4, 0.3, 0.2, 1))
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ob, None, ns, nd, dt, ctx=ctx, info=True)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=orc_ob, time_unit=1, nthreads=16, trig=1)
+    assert nrf.sum() > 800000 and np.all(st == orc.ST_EXITED)
+    assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst) and np.array_equal(info["nreflect"], nrf)
+    assert np.array_equal(m, ref)
+
+
 def test_full_size_properties(ctx, orc, arith):
     import ray_amd
     N, ns, nd, dt = 512, 2048, 2048, 1e-2
