@@ -502,6 +502,17 @@ def test_full_size_analytic_obstacle_every_ray(ctx, orc, shape):
     assert np.array_equal(m, ref)
 
 
+def test_full_size_analytic_smooth_every_ray(ctx, orc):
+    """NonObstacleDemo's analytic medium (config 1's) at the 2048 x 2048 size: every ray, every bit, from (ns, nd)."""
+    import ray_amd
+    ns, nd, dt = 2048, 2048, 1e-2
+    m, info = ray_amd.ScatterRelation(ray_amd.SinProd.smooth_demo(), None, ns, nd, dt, ctx=ctx, info=True)
+    ref, st, nst, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, dt, nthreads=16, trig=1)
+    assert np.all(st == orc.ST_EXITED)
+    assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
+    assert np.array_equal(m, ref)
+
+
 def test_full_size_properties(ctx, orc, arith):
     import ray_amd
     N, ns, nd, dt = 512, 2048, 2048, 1e-2
