@@ -1,7 +1,8 @@
 """BASELINE config 4 on one GPU: theta-blocks of the 8192 x 8192 ray sweep on the 512^2 grid -- one rank's share
 (1024 sources x 8192 directions = 8 388 608 rays, 604 MB of m) of the 8-GPU job.  No 8-GPU node is needed to run
-a shard: checked here are closed-form chords (c == 1), event status, counters, an oracle sub-sweep bit for bit,
-and that a block's rows do not depend on which block call produced them (shards abut exactly)."""
+a shard: checked here are closed-form chords (c == 1), event status, counters, an oracle sub-sweep bit for bit in both
+arithmetic flavours, the whole block against the oracle from (ns, nd) bit for bit, and that a block's rows do not
+depend on which block call produced them (shards abut exactly)."""
 import math
 
 import numpy as np
@@ -60,6 +61,12 @@ def test_c4_theta_blocks_smooth_medium(ctx, orc):
                 assert np.array_equal(a[idx], ref) and np.array_equal(ainfo["nsteps"][idx], nst)
         finally:
             ctx.set_arith(ray_amd.ARITH_FUSED)
-    # the library's own initial states are the oracle's to device-vs-host sin/cos accuracy
+    # the library's own initial states are the host-libm oracle's to the last-bit difference of two math libraries ...
     init = orc.init_states(orc.GridTables(c, EXT), NS, ND, src_begin=3 * BLOCK, src_end=3 * BLOCK + 2)
     assert np.max(np.abs(a[:2 * ND, 0:4] - init[:, 0:4])) < 1e-14
+    # ... and under the oracle's reproducible sin/cos flavour the WHOLE block call is the oracle's, from (ns, nd):
+    # all 8 388 608 rays (1.1e9 ray-steps, ~8 s of CPU on the box's 16 threads), every bit, status and step count
+    ref, st, nst, _ = orc.scatter_relation(orc.GridTables(c, EXT, 1), NS, ND, DT, src_begin=3 * BLOCK, src_end=4 * BLOCK,
+                                           nthreads=16, trig=1)
+    assert np.array_equal(ainfo["status"], st) and np.array_equal(ainfo["nsteps"], nst)
+    assert np.array_equal(a, ref)
