@@ -551,3 +551,8 @@ def test_full_size_properties(ctx, orc, arith):
     st, nst, _ = orc.shoot(tab, ref, dt, nthreads=16)
     assert np.array_equal(info["nsteps"], nst) and np.array_equal(info["status"], st)
     assert np.array_equal(ref, m)
+    # and the whole call from (ns, nd) -- BASELINE configs[1] as bench.py runs it -- against the oracle's reproducible
+    # sin/cos flavour (initial directions): every bit of the 4 194 304 x 9 result
+    ref1, st1, nst1, _ = orc.scatter_relation(tab, ns, nd, dt, nthreads=16, trig=1)
+    assert np.array_equal(info["nsteps"], nst1) and np.array_equal(info["status"], st1)
+    assert np.array_equal(ref1, m)
