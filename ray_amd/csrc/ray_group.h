@@ -15,6 +15,7 @@
 // order -- same device memory, no collective needed.
 #pragma once
 #include <rccl/rccl.h>
+#include <memory>
 #include <thread>
 
 struct GroupMember {
@@ -452,15 +453,16 @@ int ray_group_forward_operator(ray_group *g, ray_group_medium *gm, const double 
     auto work = [&](int k) {
         const GroupShare &sh = gf->share[(size_t)k];
         const int64_t n = sh.rows, ldk = std::max<int64_t>(n, 1);
-        std::vector<double> mk((size_t)ldk * 9), Xk((size_t)ldk * 4);
-        std::vector<int32_t> stk((size_t)ldk), nsk((size_t)ldk);
+        // not value-initialised: columns 5-8 of the packed rows are never read, X / status / steps are written by the call
+        std::unique_ptr<double[]> mk(new double[(size_t)ldk * 9]), Xk(new double[(size_t)ldk * 4]);
+        std::unique_ptr<int32_t[]> stk(new int32_t[(size_t)ldk]), nsk(new int32_t[(size_t)ldk]);
         for (int p = 0; p < sh.count; ++p) {
             const int64_t src = sh.row0 + (int64_t)p * sh.G * sh.nd, dst = (int64_t)p * sh.nd;
             for (int c = 0; c < 9; ++c)
                 if (c < 4 || c == 8) std::memcpy(&mk[(size_t)(dst + c * ldk)], m_host + src + (int64_t)c * ld, sizeof(double) * (size_t)sh.nd);
         }
-        rcs[(size_t)k] = ray_forward_operator(g->mem[(size_t)k].ctx, gm->med[(size_t)k], mk.data(), n, ldk, dt, droptol,
-                                               Xk.data(), ldk, nullptr, stk.data(), nsk.data(), &gf->f[(size_t)k]);
+        rcs[(size_t)k] = ray_forward_operator(g->mem[(size_t)k].ctx, gm->med[(size_t)k], mk.get(), n, ldk, dt, droptol,
+                                               Xk.get(), ldk, nullptr, stk.get(), nsk.get(), &gf->f[(size_t)k]);
         if (rcs[(size_t)k]) { errs[(size_t)k] = ray_last_error(); return; }
         for (int p = 0; p < sh.count; ++p) {
             const int64_t dst = sh.row0 + (int64_t)p * sh.G * sh.nd, src = (int64_t)p * sh.nd;
