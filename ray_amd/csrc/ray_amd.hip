@@ -83,6 +83,7 @@ struct ShootArgs {
     MediumDev med;
     int ob_kind;
     double ob_r0, ob_rho, ob_rho_n;   // circle: r0; trefoil: R, rho of the level set, rho of the normal
+    double ob_far2;                   // x^2 + y^2 above this: outside the obstacle for certain (ob > 0 without evaluating it)
     // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
     int init;
     int nd;
@@ -273,7 +274,11 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
                 st |= kStExited; active = false;
                 if (MED == kGrid) oob |= oob_hit(a.med.g, o);
             } else if (OB != kObNone) {
-                obv = ob_val<OB>(a, Xn[0], Xn[1]);
+                // only the sign of ob is ever used here (:28, :69): beyond the trefoil's largest radius it is known
+                // without the square root and the division (a wave of a coherent fan is mostly all inside or all
+                // outside: -5.3 % kernel time; for the circle the test costs more than the square root it saves)
+                if (OB == kObTrefoil && s > a.ob_far2) obv = 1.0;
+                else obv = ob_val<OB>(a, Xn[0], Xn[1]);
                 if (obv <= 0 && rfl == 0) {                                      // Obstacle.jl:69-91
                     double lo = 0, hi = 1, mid = 0.5, E[4], e;
                     int ib = 0;
@@ -1116,6 +1121,10 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     a.ob_r0 = ob ? ob->r0 : 0.0;
     a.ob_rho = ob ? ob->reserved[0] : 0.0;
     a.ob_rho_n = ob ? ob->reserved[1] : 0.0;
+    {   // the level set's largest radius (circle: r0; trefoil: R + |rho|) with a margin far above any rounding of ob
+        const double far = (std::fabs(a.ob_r0) + std::fabs(a.ob_rho)) * (1 + 1e-9);
+        a.ob_far2 = far * far * (1 + 1e-9);
+    }
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
