@@ -78,7 +78,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # the clocks of an idle GPU take about ten 4-ms launches to ramp (profiles/r2/README.md: 4.6 -> 3.66 ms per launch)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--arith", choices=["fused", "exact"], default="fused",
                     help="arithmetic flavour of the gridded kernels (include/ray_amd.h); fused is the library default")
