@@ -8,8 +8,9 @@ One "step" = one pass of the hot path over one batch of synthetic input:
   wavespeed grid (BASELINE.json configs[1]; init generated on device, outputs stay in HBM)
   + the misfit reduction against an observation resident in HBM
   + (N > 1) ONE all-reduce (RCCL) of {sum mismatch^2, sum target^2}.
-N > 1: rays shard by theta-block, rank r shoots sources [r*2048, (r+1)*2048) of a (2048*N) x 2048
-grid (weak scaling: per-GPU work fixed); no ray data is exchanged.
+N > 1: rays shard by source angle, rank r shoots the comb of sources r, r + N, ... of a (2048*N) x 2048 grid
+(2048 sources per GPU -- weak scaling: per-GPU work fixed, and equal whatever the medium's asymmetry;
+RAY_BENCH_SHARD=block selects contiguous theta-blocks instead); no ray data is exchanged.
 
 Prints ONE JSON line (rank 0).  `value` = ray-steps/s of the whole job; `roofline` prices the
 shoot kernel at SURVEY.md section 8(d)'s 225 algorithmic flop per ray-step against the fp64 VECTOR peak
