@@ -176,17 +176,22 @@ function ScatterRelationObstacle(c::Analytic, âˆ‡c, ob::Union{Circle,Trefoil}, â
 end
 
 # nd > 0: the rows of m are fans of nd directions per source (ScatterRelation's layout); a layout hint for the
-# kernel (RAY_OPT_FAN_DIRECTIONS), the results do not depend on it.
+# kernel (RAY_OPT_FAN_DIRECTIONS) for the length of this call -- without it the library looks for the fans in m
+# itself.  The results do not depend on it.
 function trace(c::Matrix{Float64}, m::AbstractMatrix{Float64}, ext::Float64, dt::Float64, mode::Cint; nd::Int = 0)
     num = size(m, 1)
-    check(ccall((:ray_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), context(), RAY_OPT_FAN_DIRECTIONS, nd))
+    nd > 0 && check(ccall((:ray_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), context(), RAY_OPT_FAN_DIRECTIONS, nd))
     mm = Matrix{Float64}(m)                       # dense column-major copy (m may be a view)
     X = Matrix{Float64}(undef, num, 4)
-    with_medium(c, ext) do med
-        check(ccall((:ray_trace_fixed_time, LIB), Cint,
-                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cdouble, Cint, Ptr{Cdouble}, Int64,
-                     Ptr{Int32}, Ptr{Int32}),
-                    context(), med, mm, num, max(num, 1), dt, mode, X, max(num, 1), C_NULL, C_NULL))
+    try
+        with_medium(c, ext) do med
+            check(ccall((:ray_trace_fixed_time, LIB), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cdouble, Cint, Ptr{Cdouble}, Int64,
+                         Ptr{Int32}, Ptr{Int32}),
+                        context(), med, mm, num, max(num, 1), dt, mode, X, max(num, 1), C_NULL, C_NULL))
+        end
+    finally
+        nd > 0 && ccall((:ray_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), context(), RAY_OPT_FAN_DIRECTIONS, 0)
     end
     X
 end

@@ -82,6 +82,8 @@ class Context:
         _lib.check(self._lib.ray_ctx_set_option(self.handle, int(option), int(value)))
         if int(option) == _lib.OPT_SOURCE_STRIDE:
             self.source_stride = int(value)
+        if int(option) == _lib.OPT_FAN_DIRECTIONS:
+            self.fan_directions = int(value)
 
     def sources_of_call(self, src_begin, src_end):
         """Number of sources a shoot of [src_begin, src_end) takes under the context's source stride."""
@@ -533,14 +535,16 @@ def _trace(c, m, ext, dt, mode, ctx, info, nd=0):
     X = np.zeros((num, 4), dtype=np.float64, order="F")
     st = np.zeros(num, dtype=np.int32)
     nst = np.zeros(num, dtype=np.int32)
-    ctx.set_option(_lib.OPT_FAN_DIRECTIONS, int(nd))
+    before = getattr(ctx, "fan_directions", 0)         # a hint the caller set on the context stays in force
+    if nd:
+        ctx.set_option(_lib.OPT_FAN_DIRECTIONS, int(nd))
     try:
         _lib.check(ctx._lib.ray_trace_fixed_time(ctx.handle, med.handle, _ptr(m), num, max(num, 1),
                                                  float(dt), mode, _ptr(X), max(num, 1), _ptr(st),
                                                  _ptr(nst)))
     finally:
         if nd:
-            ctx.set_option(_lib.OPT_FAN_DIRECTIONS, 0)
+            ctx.set_option(_lib.OPT_FAN_DIRECTIONS, before)
     return X, {"status": st, "nsteps": nst}
 
 
