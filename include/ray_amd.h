@@ -56,7 +56,15 @@ typedef struct ray_ctx    ray_ctx;     /* one per GPU */
 typedef struct ray_medium ray_medium;  /* wavespeed model resident in HBM */
 
 /* ---- context ------------------------------------------------------------------------- */
+/* 101 since ray_ctx_set_stream takes (ctx, mode, stream); 100 had (ctx, stream) -- a caller built against the older
+ * header must check the version before it passes three arguments.                                               */
 int         ray_version(void);
+/* "hip <runtime version> <path>; rccl <version> <path>": the HIP runtime and the RCCL the dynamic loader bound this
+ * library's calls to in THIS process.  A process that loaded another copy first (torch bundles its own libamdhip64 /
+ * librccl) runs the library -- ray_group's collectives included -- on that copy: a multi-GPU job wants ONE RCCL, so
+ * check this string where the job starts (bench.py prints it in its JSON line).  No
+ * counterpart in the reference (Julia's Distributed has no such ambiguity).                                       */
+int         ray_runtime_info(char *buf, size_t len);
 const char *ray_last_error(void);
 int         ray_device_count(int *n);
 int         ray_ctx_create(int device, ray_ctx **out);
@@ -387,6 +395,8 @@ int ray_group_frechet_export_csr(ray_group_frechet *f, int64_t *indptr, int32_t 
  * v / ray_mask are host arrays in the caller's row order (ray_mask: num entries or NULL = all), b / w host, N^2. */
 int ray_group_frechet_matvec_t(ray_group_frechet *f, const double *v, const uint8_t *ray_mask, double *b);
 int ray_group_frechet_normal_matvec(ray_group_frechet *f, const double *x, const uint8_t *ray_mask, double *w);
+/* valid before and after ray_group_destroy (which detaches the handle: every other call on it then reports
+ * RAY_ERR_INVALID instead of touching freed memory)                                                             */
 int ray_group_frechet_destroy(ray_group_frechet *f);
 /* the observation (NonObstacle.jl:336), rows as the LAST ray_group_shoot_to_exit / ray_group_trace_fixed_time laid
  * them out; columns 5..8 are uploaded once, sharded like m, and stay resident                                  */

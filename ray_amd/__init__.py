@@ -122,6 +122,13 @@ def host_unregister(a):
     _lib.check(_lib.load().ray_host_unregister(_ptr(a)))
 
 
+def runtime_info():
+    """Which HIP runtime and RCCL the library's calls are bound to in this process (ray_runtime_info)."""
+    buf = C.create_string_buffer(1024)
+    _lib.check(_lib.load().ray_runtime_info(buf, len(buf)))
+    return buf.value.decode()
+
+
 def device_count():
     n = C.c_int(0)
     _lib.load().ray_device_count(C.byref(n))

@@ -44,6 +44,7 @@ _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SIGNATURES = {
     "ray_version": [],
     "ray_last_error": [],
+    "ray_runtime_info": [C.c_char_p, C.c_size_t],
     "ray_linspace": [_f64, _f64, C.c_int, _vp],
     "ray_device_count": [C.POINTER(C.c_int)],
     "ray_ctx_create": [C.c_int, C.POINTER(_vp)],

@@ -4,8 +4,12 @@
 #include "ray_device.h"
 #include "ray_frechet.h"
 #include "ray_host_math.h"
+#include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -616,7 +620,8 @@ static __device__ __align__(256) double g_misfit_scratch[2 * kMisfitBlocks];
 // =============================================================================================
 static thread_local std::string g_err;
 constexpr int kMaxDevices = 64;
-static double *g_static_partial[kMaxDevices] = {};      // per device: address of g_misfit_scratch there
+static std::atomic<double *> g_static_partial[kMaxDevices];   // per device: address of g_misfit_scratch there (null until resolved)
+static std::mutex g_static_mu;                                // serialises the once-per-device resolution in ray_ctx_create
 
 static int fail(int code, const std::string &msg)
 {
@@ -819,7 +824,24 @@ static int init_tables(ray_ctx *ctx, const ray_shoot_params *p, InitTables **out
 
 extern "C" {
 
-int ray_version(void) { return 100; }
+// 101: ray_ctx_set_stream took its `mode` argument (round 2 changed the signature in place under version 100: a caller
+// built against the two-argument form must check ray_version() >= 101 before passing three)
+int ray_version(void) { return 101; }
+
+// Which HIP runtime and which RCCL this process bound the library's calls to (the dynamic loader resolves them once
+// per process: a process that loaded another copy first -- torch bundles its own -- runs the library on THAT copy).
+int ray_runtime_info(char *buf, size_t len)
+{
+    if (!buf || !len) return fail(RAY_ERR_INVALID, "ray_runtime_info: null buffer");
+    int hip_rt = 0, nccl_v = 0;
+    (void)hipRuntimeGetVersion(&hip_rt);
+    (void)ncclGetVersion(&nccl_v);
+    Dl_info a{}, b{};
+    const char *hp = dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &a) && a.dli_fname ? a.dli_fname : "?";
+    const char *np = dladdr(reinterpret_cast<void *>(&ncclAllReduce), &b) && b.dli_fname ? b.dli_fname : "?";
+    std::snprintf(buf, len, "hip %d %s; rccl %d %s", hip_rt, hp, nccl_v, np);
+    return RAY_OK;
+}
 const char *ray_last_error(void) { return g_err.c_str(); }
 
 int ray_linspace(double a, double b, int n, double *out)
@@ -856,10 +878,13 @@ int ray_ctx_create(int device, ray_ctx **out)
     if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_partial, sizeof(double) * 2 * kMisfitBlocks);
     // this device's copy of the static scratch (once per device, with the device current)
-    if (e == hipSuccess && device < kMaxDevices && !g_static_partial[device]) {
-        double *ptr = nullptr;
-        e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_misfit_scratch));
-        if (e == hipSuccess) g_static_partial[device] = ptr;
+    if (e == hipSuccess && device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_static_mu);       // two threads creating contexts on one device
+        if (!g_static_partial[device].load(std::memory_order_acquire)) {
+            double *ptr = nullptr;
+            e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_misfit_scratch));
+            if (e == hipSuccess) g_static_partial[device].store(ptr, std::memory_order_release);
+        }
     }
     if (e != hipSuccess) {
         std::string msg = std::string("ray_ctx_create: ") + hipGetErrorString(e);
@@ -1108,6 +1133,19 @@ static size_t nodes_lds_bytes(const ray_medium *med, bool fused)
     return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads(), !fused) : 0;   // no node table in kFused
 }
 
+// Wave shape of the fan mapping: a patch of 2^(6-dshift) adjacent sources x 2^dshift directions.  Default 2 x 32
+// (narrower fans touch fewer distinct cells per wave than 64 directions of one source: +3..7 % on every gridded
+// workload, profiles/r1/ablations.md); fewer directions than that -> more sources per wave; fewer sources than a
+// workgroup holds (a single fan, a group member with one or two) -> more directions per wave while there are
+// directions to take, so that the waves are full instead of carrying lanes without a source.
+static int pick_dshift(int nd, int nsrc, int wpb)
+{
+    int dshift = 5;
+    while (dshift > 2 && (1 << (dshift - 1)) >= nd) --dshift;
+    while (dshift < 6 && (wpb << (6 - dshift)) > nsrc && (1 << dshift) < nd) ++dshift;
+    return dshift;
+}
+
 // ---- shooting -----------------------------------------------------------------------------------
 static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, ShootArgs &a)
 {
@@ -1140,11 +1178,7 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
             const int v = e ? atoi(e) : 0;
             return v == 64 ? 6 : v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 0;
         }();
-        int dshift = env_dshift;
-        if (!dshift) {
-            dshift = 5;
-            while (dshift > 2 && (1 << (dshift - 1)) >= a.nd) --dshift;
-        }
+        const int dshift = env_dshift ? env_dshift : pick_dshift(a.nd, a.nsrc, wpb);
         a.dshift = dshift;
         const int spb = wpb << (6 - dshift), dpw = 1 << dshift;      // sources per block, directions per wave
         a.ngroup = (a.nsrc + spb - 1) / spb;
@@ -1417,8 +1451,7 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
         const int wpb = block_threads() / 64;
         a.nd = fan;
         a.nsrc = (int)(num / fan);
-        int dshift = 5;
-        while (dshift > 2 && (1 << (dshift - 1)) >= a.nd) --dshift;
+        const int dshift = pick_dshift(a.nd, a.nsrc, wpb);
         a.dshift = dshift;
         const int spb = wpb << (6 - dshift), dpw = 1 << dshift;
         a.ngroup = (a.nsrc + spb - 1) / spb;
@@ -2198,7 +2231,7 @@ int ray_misfit_static_dev(ray_ctx *ctx, const double *m_dev, const double *obs_d
     if (rc) return rc;
     if (num > RAY_MISFIT_STATIC_MAX_RAYS)
         return fail(RAY_ERR_UNSUPPORTED, "ray_misfit_static_dev: num exceeds RAY_MISFIT_STATIC_MAX_RAYS (2^28 rays per call)");
-    double *scratch = ctx->device < kMaxDevices ? g_static_partial[ctx->device] : nullptr;
+    double *scratch = ctx->device < kMaxDevices ? g_static_partial[ctx->device].load(std::memory_order_acquire) : nullptr;
     if (!scratch) return fail(RAY_ERR_HIP, "ray_misfit_static_dev: the static scratch of this device was not resolved");
     return misfit_launch(ctx, m_dev, obs_dev, num, ld, out_dev, mask_dev, perc_thresh, mismatch_dev, scratch);
 }

@@ -41,6 +41,7 @@ struct GroupMember {
     hipEvent_t done = nullptr;
 };
 
+struct ray_group_frechet;
 struct ray_group {
     std::vector<GroupMember> mem;
     bool use_rccl = false;
@@ -48,6 +49,9 @@ struct ray_group {
     const double **d_ptrs = nullptr;                    // fold path: the members' d_sums, on device mem[0].device
     const double **d_bptrs = nullptr;                   // fold path: the members' d_gb
     std::vector<ray_group_medium *> media;
+    std::vector<ray_group_frechet *> frechets;          // live handles: detached (g = nullptr) by ray_group_destroy
+    // which RCCL this process bound (ray_group_info): "rccl <version> <path of the library that holds ncclAllReduce>"
+    std::string rccl_info;
 };
 
 // the Frechet matrix of one ray_group_forward_operator: one ordinary ray_frechet per member over its share of the rays
@@ -99,6 +103,7 @@ static hipError_t grow(void **p, size_t *cap, size_t bytes)
 static void group_sync_all(ray_group *g)
 {
     for (GroupMember &m : g->mem) {
+        if (!m.ctx) continue;                           // ray_group_create's failure path: members not built yet
         (void)hipSetDevice(m.device);
         (void)hipStreamSynchronize(m.ctx->stream);
     }
@@ -133,6 +138,9 @@ int ray_group_destroy(ray_group *g)
         gm->med.clear();
         gm->g = nullptr;
     }
+    // the members' ray_frechet handles are detached by ray_ctx_destroy below (their destroy stays valid); the group
+    // handle over them loses its group: ray_group_frechet_destroy stays valid, every other call reports RAY_ERR_INVALID
+    for (ray_group_frechet *gf : g->frechets) gf->g = nullptr;
     for (ncclComm_t c : g->comms) (void)ncclCommDestroy(c);
     for (GroupMember &m : g->mem) {
         (void)hipSetDevice(m.device);
@@ -414,6 +422,7 @@ int ray_group_frechet_destroy(ray_group_frechet *gf)
 {
     if (!gf) return RAY_OK;
     int rc = RAY_OK;
+    if (gf->g) forget(gf->g->frechets, gf);
     for (ray_frechet *f : gf->f)
         if (f) { const int r = ray_frechet_destroy(f); if (r) rc = r; }
     delete gf;
@@ -482,6 +491,7 @@ int ray_group_forward_operator(ray_group *g, ray_group_medium *gm, const double 
             ray_group_frechet_destroy(gf);
             return fail(rc, msg);
         }
+    g->frechets.push_back(gf);
     *out = gf;
     return RAY_OK;
 }
@@ -567,6 +577,7 @@ static int group_frechet_reduce(ray_group_frechet *gf, const double *in, const u
 {
     if (!gf || !in || !out_host) return fail(RAY_ERR_INVALID, "null argument");
     ray_group *g = gf->g;
+    if (!g) return fail(RAY_ERR_INVALID, "the group of this ray_group_frechet was destroyed: only ray_group_frechet_destroy is valid on it");
     const int G = (int)g->mem.size();
     const size_t nn = (size_t)gf->N * (size_t)gf->N;
     int rc;

@@ -76,6 +76,12 @@ def download(ptr, count, dtype):
     return out
 
 
+def mem_free_bytes():
+    free, total = C.c_size_t(), C.c_size_t()
+    _ok(hip().hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value
+
+
 def stream_create(nonblocking=True):
     s = C.c_void_p()
     _ok(hip().hipStreamCreateWithFlags(C.byref(s), C.c_uint(1 if nonblocking else 0)), "hipStreamCreateWithFlags")

@@ -64,7 +64,7 @@ def test_linspace_matches_oracle(orc):
 def test_version_and_struct_layout():
     from ray_amd import _lib
     lib = _lib.load()
-    assert lib.ray_version() >= 100
+    assert lib.ray_version() >= 101              # 101: ray_ctx_set_stream(ctx, mode, stream)
     assert C.sizeof(_lib.Obstacle) == 32 and C.sizeof(_lib.ShootParams) == 48 and C.sizeof(_lib.Counters) == 32
 
 
@@ -87,6 +87,27 @@ def test_fails_loudly_without_gpu():
     assert lib.ray_trace_fixed_time(None, None, None, 0, 0, 0.1, 0, None, 0, None, None) != 0
     assert lib.ray_misfit(None, None, None, 0, 0, None, None, 0.2, None) != 0
     assert lib.ray_medium_create_grid(None, None, 8, 1.5, C.byref(z)) != 0 and not z.value
+
+
+def test_group_create_failure_returns_an_error():
+    """ray_group_create whose member contexts cannot be built (a device index that does not exist; here or on a box
+    with one GPU) must come back with an error code and *out == NULL -- its clean-up used to dereference the
+    members that had no context yet."""
+    from ray_amd import _lib
+    lib = _lib.load()
+    for devs in ([63], [0, 63], [62, 63, 61]):
+        h = C.c_void_p(1)
+        arr = (C.c_int * len(devs))(*devs)
+        rc = lib.ray_group_create(arr, len(devs), C.byref(h))
+        assert rc != 0 and not h.value and len(lib.ray_last_error()) > 0
+    h = C.c_void_p(1)
+    assert lib.ray_group_create(None, 0, C.byref(h)) != 0 and not h.value
+
+
+def test_runtime_info_names_the_bound_libraries():
+    import ray_amd
+    info = ray_amd.runtime_info()
+    assert info.startswith("hip ") and "; rccl " in info and "librccl" in info and "libamdhip64" in info
 
 
 def test_markstein_quotients_equal_ieee_division(tmp_path):

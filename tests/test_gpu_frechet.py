@@ -345,3 +345,37 @@ def test_forward_operator_random_media(ctx, orc, arith, seed):
     assert np.array_equal(s[:, 4:8], Xo)
     assert np.max(np.abs(info["rho"] - rho_o)) <= MTOL * np.max(np.abs(rho_o))
     assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+
+
+def test_forward_operator_n513_entry_for_entry(ctx, orc, arith):
+    """The Frechet matrix at the grid size the build is timed on (N = 513, dt = 1e-2: the 32-bit sort keys, ~130 steps
+    for the longest rays), entry for entry against the C oracle's dense rows: 64 rays of 2 sources x 32 directions, from
+    grazing chords of ~20 steps to diameters of ~200 (8.4 MB of dense oracle rows per ray)."""
+    import ray_amd
+    import scipy.sparse as sps
+    N, dt = 513, 1e-2
+    c, tab, m = _data(orc, N, 2, 32, arith)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt, nthreads=16)
+    assert nso.min() <= 25 and nso.max() >= 120
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    M, s, info = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    assert np.array_equal(info["nsteps"], nso) and np.array_equal(info["status"], sto)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(info["rho"] - rho_o)) <= MTOL * np.max(np.abs(rho_o))
+    scale = float(np.max(np.abs(Mo)))
+    Mo = sps.csr_matrix(Mo)                                        # the dense rows are 540 MB: compare sparse
+    D = (M - Mo).tocoo()
+    assert (np.max(np.abs(D.data)) if D.nnz else 0.0) <= MTOL * scale
+    # every stencil node the oracle touched is a stored entry of the device matrix (droptol = None keeps exact zeros too)
+    Mo.eliminate_zeros()
+    pat_o = sps.csr_matrix((np.ones(Mo.nnz), Mo.indices, Mo.indptr), shape=Mo.shape)
+    pat_m = sps.csr_matrix((np.ones(M.nnz), M.indices, M.indptr), shape=M.shape)
+    assert M.nnz >= Mo.nnz and pat_o.multiply(pat_m).nnz == Mo.nnz
+    # with the reference's droptol (1e-12, NonObstacle.jl:242) the stored pattern is the oracle's filtered one
+    Md, _ = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx)
+    keep = Mo.copy()
+    keep.data[np.abs(keep.data) <= 1e-12] = 0.0
+    keep.eliminate_zeros()
+    pat_d = sps.csr_matrix((np.ones(Md.nnz), Md.indices, Md.indptr), shape=Md.shape)
+    pat_k = sps.csr_matrix((np.ones(keep.nnz), keep.indices, keep.indptr), shape=keep.shape)
+    assert abs(pat_d - pat_k).sum() <= 1e-5 * keep.nnz              # entries within rounding of the threshold may differ

@@ -158,3 +158,35 @@ def test_group_forward_operator_reproduces_single_context(ctx, orc, devices):
             g.ScatterForwardOperator(g.sinprod_medium(ray_amd.SinProd.smooth_demo()), data, 5e-2)
     finally:
         g.close()
+
+
+def test_group_create_with_a_missing_device_fails_cleanly(ctx):
+    """the failure path of ray_group_create (member k built, k+1.. not) returns an error, no crash."""
+    import ray_amd
+    for devs in ([63], [0, 63]):
+        with pytest.raises(ray_amd.RayError):
+            ray_amd.Group(devs)
+    g = ray_amd.Group([0])                       # and the library still works afterwards
+    assert g.size == 1
+    g.close()
+
+
+def test_group_frechet_outlives_its_group(ctx, orc):
+    """a GroupFrechetMatrix whose group was closed reports an error on every pass (it used to read freed
+    memory) and can still be destroyed."""
+    import ray_amd
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, 31, 1.5)
+    m, *_ = orc.scatter_relation(orc.SMOOTH_DEMO, 3, 8, 1e-2)
+    g = ray_amd.Group([0, 0])
+    med = g.grid_medium(c, 1.5)
+    M, s = g.ScatterForwardOperator(med, np.asfortranarray(m), 5e-2, nd=8)
+    b = M.matvec_t(np.ones(M.shape[0]))
+    assert np.isfinite(b).all() and np.abs(b).max() > 0
+    g.close()
+    with pytest.raises(ray_amd.RayError):
+        M.matvec_t(np.ones(M.shape[0]))
+    with pytest.raises(ray_amd.RayError):
+        M.normal_matvec(np.ones(M.shape[1]))
+    with pytest.raises(ray_amd.RayError):
+        M.tocsr()
+    M.close()

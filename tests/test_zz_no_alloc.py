@@ -29,11 +29,19 @@ def test_static_misfit_matches_misfit_dev_twice(ctx, orc):
     host_m = np.asfortranarray(rng.standard_normal((ld, 9)))
     host_o = np.asfortranarray(host_m + 0.15 * rng.standard_normal((ld, 9)) * rng.random((ld, 1)))
     m, obs = hiprt.DevBuf.from_numpy(host_m), hiprt.DevBuf.from_numpy(host_o)     # column-major (ld, 9)
+    scratch_out = hiprt.DevBuf.from_numpy(np.zeros(2))
     for num in (300001, 4097, 0):                                       # big, then smaller, then empty
         want = _run(lib, ctx, lib.ray_misfit_dev, m, obs, num, ld, 0.2)
         got = _run(lib, ctx, lib.ray_misfit_static_dev, m, obs, num, ld, 0.2)
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+        # the property the entry point exists for: a warm call allocates nothing on the device
+        free0 = hiprt.mem_free_bytes()
+        rc = lib.ray_misfit_static_dev(ctx.handle, m.ptr, obs.ptr, num, ld, scratch_out.ptr, None, 0.2, None)
+        assert rc == 0, lib.ray_last_error()
+        ctx.synchronize()
+        assert hiprt.mem_free_bytes() == free0
+        assert np.array_equal(scratch_out.to_numpy(np.float64, 2), got[0])
         # and against the oracle (the existing entry point's own bar)
         mism, out, mask = orc.misfit(np.asfortranarray(host_m[:num]), np.asfortranarray(host_o[:num]), 0.2)
         assert np.array_equal(got[2], mism) and np.array_equal(got[1], mask)
