@@ -75,6 +75,93 @@ def recorded_traffic():
     return d.get("traffic_bytes_per_launch"), d.get("l2_hit_rate"), d.get("kernel_avg_ms"), src
 
 
+def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p, reps=4):
+    """The other kernels of the hot path on the driver's clock: timed in this process after the
+    headline loop, HIP events around every launch (the library's counters), few launches each, clocks already warm.
+    `value` / `roofline` of the line are untouched by this.  Every entry: kernel_ms (average), ray_steps per launch,
+    ray_steps_per_s; `frac` where SURVEY.md section 8(d) defines a flop count (gridded RK4: 225 per ray-step)."""
+    out = {}
+    nrf = torch.empty(num, dtype=torch.int32, device=dev)
+    X = torch.empty(4 * num, dtype=torch.float64, device=dev)
+
+    def timed(fn, n=reps):
+        fn()
+        ctx.synchronize()
+        ctx.reset_counters()
+        ctx.enable_timing(True)
+        for _ in range(n):
+            fn()
+        c = ctx.counters()
+        ctx.enable_timing(False)
+        ms = c["kernel_ms"] / max(c["launches"], 1)
+        steps = c["ray_steps"] / max(c["launches"], 1)
+        return {"kernel_ms": ms, "launches": int(c["launches"]), "ray_steps": int(steps), "ray_steps_per_s": steps / (ms * 1e-3),
+                "rays_per_s": num / (ms * 1e-3)}
+
+    def shoot(med, ob, tu):
+        return lambda: rdev.shoot_to_exit_dev(ctx, med, NS_PER_GPU, ND, DT, m.data_ptr(), num, ob=ob, time_unit=tu,
+                                              status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr(), nreflect_ptr=nrf.data_ptr())
+
+    # BASELINE configs[2] at its timing size: ObstacleDemo's analytic medium around the circle r0 = 0.3, t in steps
+    e = timed(shoot(ray_amd.SinProd.obstacle_demo(), ray_amd.Circle(0.3), ray_amd.TIME_STEPS))
+    e.update(workload="config 3: analytic SinProd(0.2,2pi,pi) + circle 0.3, 2048x2048 rays, dt=1e-2 (k_shoot<sinprod,circle>)",
+             reflections=int(nrf.sum().item()), not_exited=int((status != ray_amd.ST_EXITED).sum().item()))
+    out["config3_analytic_circle"] = e
+    # config 1's medium at the same size (what ScatterRelation runs in NonObstacleDemo.jl)
+    e = timed(shoot(ray_amd.SinProd.smooth_demo(), None, ray_amd.TIME_SECONDS))
+    e.update(workload="analytic SinProd(0.3,1.5pi,1.5pi), 2048x2048 rays, dt=1e-2 (k_shoot<sinprod,none>)",
+             not_exited=int((status != ray_amd.ST_EXITED).sum().item()))
+    out["analytic_smooth"] = e
+    # a9: the trajectory part of ScatterForwardOperator for the rays just shot, on a perturbed gridded model, fan hint
+    c0 = np.asfortranarray([[0.85 * ray_amd.SinProd.smooth_demo()(float(x), float(y)) + 0.1 for y in p] for x in p])
+    med0 = ray_amd.GridMedium(c0, EXT, ctx)
+    ctx.set_option(ray_amd._lib.OPT_FAN_DIRECTIONS, ND)
+    try:
+        e = timed(lambda: rdev.trace_fixed_time_dev(ctx, med0, m.data_ptr(), num, num, DT, ray_amd.TRACE_SHORTEN_CEASE, X.data_ptr(), num,
+                                                    status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr()))
+    finally:
+        ctx.set_option(ray_amd._lib.OPT_FAN_DIRECTIONS, 0)
+    e.update(workload="a9 ChunkProcessing! trajectories, 2048x2048 rays, N=512, dt=1e-2, fan hint (k_trace)",
+             frac=F_STEP_GRID * e["ray_steps_per_s"] / 1e12 / FP64_VECTOR_PEAK)
+    out["trace_a9_fan"] = e
+    # NEXT-1: the complete ScatterForwardOperator build (X, rho, Frechet block rows) at 512 x 512 rays, N = 513
+    ns2 = nd2 = 512
+    mh = ray_amd.ScatterRelation(ray_amd.SinProd.smooth_demo(), None, ns2, nd2, DT, ctx=ctx)
+    p2 = np.zeros(513)
+    ray_amd._lib.check(ctx._lib.ray_linspace(-EXT, EXT, 513, p2.ctypes.data))
+    med2 = ray_amd.GridMedium(np.asfortranarray([[ray_amd.SinProd.smooth_demo()(float(x), float(y)) for y in p2] for x in p2]), EXT, ctx)
+    ray_amd.forward_operator_dev(med2, mh, EXT, DT, ctx=ctx, want_rho=False)[0].close()         # sizes the workspaces
+    ctx.reset_counters()
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    F, _, _, info = ray_amd.forward_operator_dev(med2, mh, EXT, DT, ctx=ctx, want_rho=False)
+    call_s = time.perf_counter() - t0
+    c = ctx.counters()
+    ctx.enable_timing(False)
+    steps = int(info["nsteps"].astype(np.int64).sum())
+    out["frechet_build"] = {"workload": "ScatterForwardOperator build (k_frechet + merge -> device block rows), 512x512 rays, N=513, dt=1e-2",
+                            "kernel_ms": c["kernel_ms"], "ray_steps": steps, "ray_steps_per_s": steps / (c["kernel_ms"] * 1e-3),
+                            "nnz": int(F.nnz), "call_ms_host_pointers": call_s * 1e3}
+    # NEXT-2: the inner loop of the matrix-free solve on that matrix, w = M'(M x)
+    x = torch.randn(513 * 513, dtype=torch.float64, device=dev) * 1e-2
+    w = torch.empty_like(x)
+    n_entries = F.block_rows_dev()[0]
+    rdev.frechet_normal_matvec_dev(F, x.data_ptr(), 0, w.data_ptr())
+    ctx.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        rdev.frechet_normal_matvec_dev(F, x.data_ptr(), 0, w.data_ptr())
+    e1.record()
+    e1.synchronize()
+    nm_ms = e0.elapsed_time(e1) / reps
+    out["normal_matvec"] = {"workload": "w = M'(M x) on the block rows of that matrix (k_br_normal_matvec)", "kernel_ms": nm_ms,
+                            "block_row_entries": int(n_entries), "algorithmic_bytes": int(n_entries) * 36 * 2,
+                            "hbm_frac": int(n_entries) * 36 * 2 / (nm_ms * 1e-3) / 8.0e12}
+    F.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +169,8 @@ def main():
     # the clocks of an idle GPU take about ten 4-ms launches to ramp (profiles/r2/README.md: 4.6 -> 3.66 ms per launch)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary kernels (config 3, analytic smooth, a9 trace, Frechet build) timed after the headline loop")
     ap.add_argument("--arith", choices=["fused", "exact"], default="fused",
                     help="arithmetic flavour of the gridded kernels (include/ray_amd.h); fused is the library default")
     args = ap.parse_args()
@@ -171,6 +260,11 @@ def main():
     # (gpurun_out/r2/bench_2r*.err) -- and is not a path the product uses.
     # RAY_BENCH_HOST_REDUCE=0 / 1 overrides.
     host_reduce = os.environ.get("RAY_BENCH_HOST_REDUCE", "1" if backend == "gloo" else "0") == "1"
+    if backend == "gloo" and not host_reduce:
+        raise SystemExit("RAY_BENCH_BACKEND=gloo with RAY_BENCH_HOST_REDUCE=0 is refused: ProcessGroupGloo's all_reduce of a "
+                         "DEVICE tensor blocks both ranks for good when they share one GPU "
+                         "(profiles/r2/gloo_device_allreduce_hang_trace.txt; DESIGN.md section 6).  The rehearsal reduces a host "
+                         "copy; the real run uses RCCL on the device tensor.")
 
     def allreduce(t, op=None):
         """One all-reduce of a small device tensor (see host_reduce above)."""
@@ -282,6 +376,9 @@ def main():
                          "flop_per_ray_step": F_STEP_GRID,
                          "kernel_ray_steps_per_s": steps_per_launch / kern_s},
         }
+        out["runtime"] = ray_amd.runtime_info()        # which HIP runtime / RCCL this process bound
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -143,6 +143,7 @@ int ray_group_destroy(ray_group *g)
     for (ray_group_frechet *gf : g->frechets) gf->g = nullptr;
     for (ncclComm_t c : g->comms) (void)ncclCommDestroy(c);
     for (GroupMember &m : g->mem) {
+        if (!m.ctx) continue;                           // never built (ray_group_create's failure path): owns nothing
         (void)hipSetDevice(m.device);
         if (m.d_m) (void)hipFree(m.d_m);
         if (m.d_int) (void)hipFree(m.d_int);
@@ -154,8 +155,9 @@ int ray_group_destroy(ray_group *g)
         if (m.d_gmask) (void)hipFree(m.d_gmask);
         if (m.d_gb) (void)hipFree(m.d_gb);
         if (m.done) (void)hipEventDestroy(m.done);
-        if (m.ctx) ray_ctx_destroy(m.ctx);
+        ray_ctx_destroy(m.ctx);
     }
+    (void)hipGetLastError();                            // nothing of the tear-down is left for a later launch check to trip over
     if (g->d_ptrs) { (void)hipSetDevice(g->mem[0].device); (void)hipFree(g->d_ptrs); }
     if (g->d_bptrs) { (void)hipSetDevice(g->mem[0].device); (void)hipFree(g->d_bptrs); }
     delete g;
