@@ -5,6 +5,7 @@ Run from the repo root:  python oracle/gen_golden.py            (all fixtures)
                          python oracle/gen_golden.py radial     (only the radial-sine-sum ones, added later)
                          python oracle/gen_golden.py trefoil_grid   (grid + trefoil "identity" flavour, round 2)
                          python oracle/gen_golden.py rep        (analytic media, reproducible sin/cos flavour, round 2)
+                         python oracle/gen_golden.py fused      (analytic media, the kernels' default fused flavour, round 3)
 The fixtures are data only (inputs + expected outputs).  They pin the C oracle and the HIP
 path to the Python reading of the reference; the reference itself ships no vectors
 ("parity unpinned" by the reference).
@@ -90,8 +91,29 @@ def rep():
              **pack(rows, P.shoot(so, rows, dt, obstacle=tf, time_unit=1)))
 
 
+def fused():
+    # G1h (round 3): the shipped analytic media under the kernels' DEFAULT flavour of Hamilton -- multiply-adds contracted,
+    #      sin/cos anchors shared by consecutive steps (ray_oracle.py hamilton_fused / _rk4_fused, exact-rational fma) --
+    #      the smooth demo, and the obstacle demo around the shipped circle: the C oracle (arith = 1, trig = 1) and the
+    #      HIP kernels must reproduce every bit and every event
+    ns, nd, dt = 8, 16, 1e-2
+    sp = P.SinProd.smooth_demo()
+    sp.trig = "fused"
+    rows = P.init_states(sp, ns, nd, 0.0, pi)
+    np.savez(os.path.join(OUT, "scatter_smooth_fused_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt,
+             params=np.array([sp.A, sp.wx, sp.wy, sp.gx, sp.gy]), **pack(rows, P.shoot(sp, rows, dt)))
+    so = P.SinProd.obstacle_demo()
+    so.trig = "fused"
+    rows = P.init_states(so, ns, nd, 0.0, pi)
+    np.savez(os.path.join(OUT, "scatter_obstacle_fused_ns8_nd16.npz"), ns=ns, nd=nd, dt=dt, r0=0.3,
+             params=np.array([so.A, so.wx, so.wy, so.gx, so.gy]),
+             **pack(rows, P.shoot(so, rows, dt, obstacle=P.Circle(0.3), time_unit=1)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["fused"]:
+        return fused()
     if sys.argv[1:] == ["rep"]:
         return rep()
     if sys.argv[1:] == ["trefoil"]:
@@ -104,6 +126,7 @@ def main():
     trefoil_grid()
     radial()
     rep()
+    fused()
     ns, nd, dt = 8, 16, 1e-2
 
     # G1a: smooth demo medium, analytic, ScatterRelation (NonObstacleDemo.jl:32)

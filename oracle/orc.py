@@ -176,9 +176,11 @@ def radial_grid(terms, N, ext):
     return c
 
 
-def _medium(med, trig=0):
+def _medium(med, trig=0, arith=None):
     """trig: 0 = sin/cos of the host libm (as the reference calls its own), 1 = the reproducible flavour of
-    ray_oracle.c, the sequence the HIP kernels evaluate (analytic media and the initial directions)."""
+    ray_oracle.c, the sequence the HIP kernels evaluate (analytic media and the initial directions).
+    arith (analytic media; a GridTables carries its own): 0 = Hamilton as written, 1 = the "fused" flavour of
+    ray_oracle.c (multiply-adds contracted, sin/cos anchors shared by consecutive steps; needs trig = 1)."""
     if isinstance(med, tuple) and med and isinstance(med[0], tuple):
         m = radial_medium(med)
     elif isinstance(med, GridTables):
@@ -188,6 +190,9 @@ def _medium(med, trig=0):
     else:
         m = analytic_medium(med)
     m.trig = int(trig)
+    if arith is not None and m.kind != 1:
+        assert not arith or trig, "the fused analytic flavour is defined on the reproducible sin/cos (trig = 1)"
+        m.arith = int(arith)
     return m
 
 
@@ -195,6 +200,16 @@ def rep_sincos(a):
     s, c = C.c_double(), C.c_double()
     lib().orc_rep_sincos(C.c_double(a), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def rep_shift_fused(s0, c0, d):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_rep_shift_fused(C.c_double(s0), C.c_double(c0), C.c_double(d), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def anchor_period(w, dt, cmax):
+    return int(lib().orc_anchor_period(C.c_double(w), C.c_double(dt), C.c_double(cmax)))
 
 
 def rep_shift(s0, c0, d):
@@ -214,14 +229,14 @@ def init_states(med, ns, nd, dir_lo=0.0, dir_hi=np.pi, src_begin=0, src_end=None
     return m
 
 
-def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=1, trig=0):
+def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=1, trig=0, arith=None):
     """In-place on m (Fortran (num,9)); returns (status, nsteps, nreflect)."""
     assert m.flags.f_contiguous and m.dtype == np.float64 and m.shape[1] == 9
     num = m.shape[0]
     st = np.zeros(num, dtype=np.int32)
     ns_ = np.zeros(num, dtype=np.int32)
     nr = np.zeros(num, dtype=np.int32)
-    mm = _medium(med, trig)
+    mm = _medium(med, trig, arith)
     ob = _obstacle(obstacle_r0)
     lib().orc_shoot(C.byref(mm), C.byref(ob), C.c_double(dt), C.c_int(time_unit),
                     C.c_int(max_steps), _dp(m), C.c_int64(num), C.c_int64(num), _dp(st), _dp(ns_),
@@ -230,9 +245,9 @@ def shoot(med, m, dt, obstacle_r0=None, time_unit=0, max_steps=100000, nthreads=
 
 
 def scatter_relation(med, ns, nd, dt, dir_lo=0.0, dir_hi=np.pi, obstacle_r0=None, time_unit=0,
-                     src_begin=0, src_end=None, max_steps=100000, nthreads=1, trig=0):
+                     src_begin=0, src_end=None, max_steps=100000, nthreads=1, trig=0, arith=None):
     m = init_states(med, ns, nd, dir_lo, dir_hi, src_begin, src_end, trig)
-    st, nsteps, nref = shoot(med, m, dt, obstacle_r0, time_unit, max_steps, nthreads, trig)
+    st, nsteps, nref = shoot(med, m, dt, obstacle_r0, time_unit, max_steps, nthreads, trig, arith)
     return m, st, nsteps, nref
 
 

@@ -304,6 +304,29 @@ void orc_rep_shift(double s0, double c0, double d, double *sn, double *cs)
     *sn = s0 + fma(c0, sd, -(s0 * v));
     *cs = c0 - fma(s0, sd, c0 * v);
 }
+/* the same advance with its multiply-adds contracted (the kernels' kFused analytic flavour, ray_trig.h shift_fused) */
+void orc_rep_shift_fused(double s0, double c0, double d, double *sn, double *cs)
+{
+    static const double Ts[5] = {-1.66666666666666666667e-01, 8.33333333333333333333e-03, -1.98412698412698412698e-04,
+                                 2.75573192239858906526e-06, -2.50521083854417187751e-08};
+    static const double Tc[6] = {0.5, -4.16666666666666666667e-02, 1.38888888888888888889e-03, -2.48015873015873015873e-05,
+                                 2.75573192239858906526e-07, -2.08767569878680989792e-09};
+    double z = d * d;
+    double ps = Ts[4];
+    for (int k = 3; k >= 0; --k) ps = fma(z, ps, Ts[k]);
+    double sd = fma(d * z, ps, d);                                /* sin d */
+    double pc = Tc[5];
+    for (int k = 4; k >= 0; --k) pc = fma(z, pc, Tc[k]);
+    double v = z * pc;                                            /* 1 - cos d */
+    *sn = fma(c0, sd, fma(-s0, v, s0));
+    *cs = fma(-s0, sd, fma(-c0, v, c0));
+}
+/* steps one full evaluation anchors (ray_trig.h anchor_period): the argument w x moves by at most |w| dt cmax a step */
+int orc_anchor_period(double w, double dt, double cmax)
+{
+    double k = floor(0.24 / (fabs(w) * dt * cmax));
+    return k >= 64.0 ? 64 : (k >= 1.0 ? (int)k : 1);
+}
 static double med_sin(const orc_medium *med, double a)
 {
     if (!med->trig) return sin(a);
@@ -433,6 +456,104 @@ void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
     hamilton_radial(X, &med, H);
 }
 
+/* ---- "fused" flavour of the analytic right-hand sides (med->arith == 1, kinds 0 and 2) -------------------------
+ * Hamilton is @fastmath in the reference (NonObstacle.jl:1), so its multiply-adds may be contracted.  This flavour
+ * spells out the evaluation the HIP kernels use by default (ray_device.h rhs_sinprod / rhs_radial<kFused>):
+ *   - sin/cos: the reproducible evaluation above; a full evaluation ANCHORS the advances of K consecutive steps
+ *     (orc_anchor_period: the argument cannot leave the advance's range in K steps), every other look-up is ONE
+ *     contracted advance from the anchor, argument difference d = fma(w, x, -anchor); a look-up beyond the range
+ *     evaluates in full and -- at a first stage -- re-anchors;
+ *   - speed = fma(A sx, sy, 1), tau = fma(py, py, px px), H[2:3] = ((-g) (speed tau)) (cos sin);
+ *   - the RK4 combination of the gridded fused flavour: Y = fma(H, dt/2, X), Xn = fma(sum, dt RN(1/6), X).        */
+typedef struct { double base[12]; int acnt[4]; int K[4]; } trig_state;
+static void trig_state_init(trig_state *ts, const orc_medium *med, double dt)
+{
+    memset(ts, 0, sizeof *ts);
+    for (int k = 0; k < 4; ++k) ts->K[k] = 1;
+    if (med->kind == 0) {
+        double cmax = 1 + fabs(med->sp.A);
+        ts->K[0] = orc_anchor_period(med->sp.wx, dt, cmax);
+        ts->K[1] = orc_anchor_period(med->sp.wy, dt, cmax);
+    } else if (med->kind == 2) {
+        double cmax = 1;
+        for (int k = 0; k < med->rad.K; ++k) cmax += fabs(med->rad.a[k]);
+        for (int k = 0; k < med->rad.K; ++k) ts->K[k] = orc_anchor_period(M_PI, dt, cmax);
+    }
+}
+static void fused_stage(int stage, int anchor, double w, double x, double base[3], double *sn, double *cs)
+{
+    if (stage == 0 && anchor) {
+        double a = w * x;
+        orc_rep_sincos(a, sn, cs);
+        base[0] = a; base[1] = *sn; base[2] = *cs;
+        return;
+    }
+    double d = fma(w, x, -base[0]);
+    if (fabs(d) <= REP_SHIFT_MAX) { orc_rep_shift_fused(base[1], base[2], d, sn, cs); return; }
+    double a = w * x;
+    orc_rep_sincos(a, sn, cs);
+    if (stage == 0) { base[0] = a; base[1] = *sn; base[2] = *cs; }
+}
+static void hamilton_sinprod_fused(const double X[4], const orc_sinprod *sp, int stage, unsigned anchor, double base[12], double H[4])
+{
+    double sx, cx, sy, cy;
+    fused_stage(stage, anchor & 1u, sp->wx, X[0], base, &sx, &cx);
+    fused_stage(stage, anchor & 2u, sp->wy, X[1], base + 3, &sy, &cy);
+    double speed = fma(sp->A * sx, sy, 1.0);
+    double tau = fma(X[3], X[3], X[2] * X[2]);
+    double s2 = speed * speed, w = speed * tau;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = ((-sp->gx) * w) * (cx * sy);
+    H[3] = ((-sp->gy) * w) * (sx * cy);
+}
+static void hamilton_radial_fused(const double X[4], const orc_medium *med, int stage, unsigned anchor, double base[12], double H[4])
+{
+    const orc_radial *rd = &med->rad;
+    double speed = 1.0, g0 = 0, g1 = 0;
+    for (int k = 0; k < rd->K; ++k) {
+        double dx = X[0] - rd->x[k], dy = X[1] - rd->y[k];
+        double r = sqrt(fma(dy, dy, dx * dx));
+        double sn, cs;
+        fused_stage(stage, anchor & (1u << k), M_PI, r, base + 3 * k, &sn, &cs);
+        double f = ((rd->a[k] * M_PI) * cs) / r;
+        speed = fma(rd->a[k], sn, speed);
+        g0 = fma(f, dx, g0);
+        g1 = fma(f, dy, g1);
+    }
+    double s2 = speed * speed;
+    double tau = fma(X[3], X[3], X[2] * X[2]);
+    double w = speed * tau;
+    H[0] = s2 * X[2];
+    H[1] = s2 * X[3];
+    H[2] = (-g0) * w;
+    H[3] = (-g1) * w;
+}
+static void rk4_step_analytic_fused(const orc_medium *med, double X[4], double dt, trig_state *ts)
+{
+    double H[4], Y[4], acc[4];
+    const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
+    unsigned anchor = 0;
+    for (int k = 0; k < (med->kind == 0 ? 2 : 4); ++k) {
+        if (ts->acnt[k] == 0) { anchor |= 1u << k; ts->acnt[k] = ts->K[k]; }
+        --ts->acnt[k];
+    }
+#define RHS_F(P, STAGE)                                                                     \
+    do {                                                                                    \
+        if (med->kind == 0) hamilton_sinprod_fused(P, &med->sp, STAGE, anchor, ts->base, H); \
+        else hamilton_radial_fused(P, med, STAGE, anchor, ts->base, H);                     \
+    } while (0)
+    RHS_F(X, 0);
+    for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma(H[k], hdt, X[k]); }
+    RHS_F(Y, 1);
+    for (int k = 0; k < 4; ++k) { acc[k] = fma(2.0, H[k], acc[k]); Y[k] = fma(H[k], hdt, X[k]); }
+    RHS_F(Y, 2);
+    for (int k = 0; k < 4; ++k) { acc[k] = fma(2.0, H[k], acc[k]); Y[k] = fma(H[k], dt, X[k]); }
+    RHS_F(Y, 3);
+    for (int k = 0; k < 4; ++k) X[k] = fma(acc[k] + H[k], dt6, X[k]);
+#undef RHS_F
+}
+
 /* stage = 0..3 inside an RK4 step, base = the step's scratch (the reproducible sinprod flavour only) */
 static int rhs(const orc_medium *med, const double X[4], double H[4], int stage, double base[12])
 {
@@ -520,12 +641,13 @@ void orc_ob_normal(const orc_obstacle *ob, double x, double y, double n[2]) { ob
 
 /* one classical RK4 step in the a6/a7 form: k = H*dt, X + k1/2, ... /6.0
  * (NonObstacle.jl:72-76; Obstacle.jl:34-38) */
-static int rk4_step_kdt(const orc_medium *med, double X[4], double dt)
+static int rk4_step_kdt(const orc_medium *med, double X[4], double dt, trig_state *ts)
 {
     double k1[4], k2[4], k3[4], k4[4], Y[4], H[4], base[12];
     int oob = 0;
     if (med->kind == 1 && med->arith == 1)
         return rk4_step_fused(med->eval, med->grad, med->p, med->N, X, dt);
+    if (med->arith == 1) { rk4_step_analytic_fused(med, X, dt, ts); return 0; }
     oob |= rhs(med, X, H, 0, base);
     for (int k = 0; k < 4; ++k) { k1[k] = H[k] * dt; Y[k] = X[k] + k1[k] / 2; }
     oob |= rhs(med, Y, H, 1, base);
@@ -549,11 +671,13 @@ static void shoot_one(const orc_medium *med, const orc_obstacle *ob, double dt, 
     double t = 0;
     int rfl = 0, st = 0, steps = 0, nref = 0;
     const int has_ob = ob && ob->kind != 0;
+    trig_state ts;
+    trig_state_init(&ts, med, dt);
     for (;;) {
         if (steps >= max_steps) { st |= ORC_ST_STEP_CAP; break; }
         if (has_ob && ob_val(ob, X[0], X[1]) > 0) rfl = 0;          /* Obstacle.jl:28-30 */
         for (int k = 0; k < 4; ++k) prev[k] = X[k];
-        if (rk4_step_kdt(med, X, dt)) st |= ORC_ST_OOB;
+        if (rk4_step_kdt(med, X, dt, &ts)) st |= ORC_ST_OOB;
         ++steps;
         t = time_unit ? t + 1 : t + dt;            /* Obstacle.jl:39 / NonObstacle.jl:77 */
         if (norm2(X[0], X[1]) >= 1) {              /* NonObstacle.jl:78-93; Obstacle.jl:40-57 */

@@ -64,7 +64,9 @@ typedef struct {
     orc_sinprod sp;
     int N; double ext;     /* grid */
     const double *eval, *grad, *p;
-    int arith;             /* grid only: 0 = as written (un-fused), 1 = "fused" flavour (ray_oracle.c) */
+    int arith;             /* 0 = as written (un-fused), 1 = "fused" flavour (ray_oracle.c): grid -- contracted DiscreteHamilton
+                            * and RK4 combination; analytic kinds (with trig = 1) -- contracted Hamilton, sin/cos anchors
+                            * shared by consecutive steps, the same RK4 combination */
     orc_radial rad;
     int trig;              /* sin/cos of the analytic media and of the initial directions: 0 = the host libm (the
                               reference calls Julia's sin/cos), 1 = the "reproducible" flavour (ray_oracle.c: a fixed

@@ -84,6 +84,46 @@ def rep_shift(s0, c0, d):
     return s0 + _fma(c0, sd, -(s0 * v)), c0 - _fma(s0, sd, c0 * v)
 
 
+def rep_shift_fused(s0, c0, d):
+    """rep_shift with its multiply-adds contracted (ray_trig.h shift_fused; ray_oracle.c orc_rep_shift_fused)."""
+    z = d * d
+    ps = _TS[4]
+    for k in (3, 2, 1, 0):
+        ps = _fma(z, ps, _TS[k])
+    sd = _fma(d * z, ps, d)
+    pc = _TC[5]
+    for k in (4, 3, 2, 1, 0):
+        pc = _fma(z, pc, _TC[k])
+    v = z * pc
+    return _fma(c0, sd, _fma(-s0, v, s0)), _fma(-s0, sd, _fma(-c0, v, c0))
+
+
+def anchor_period(w, dt, cmax):
+    """steps one full sin/cos evaluation anchors in the fused analytic flavour (ray_trig.h anchor_period)."""
+    k = floor(0.24 / (abs(w) * dt * cmax))
+    return 64 if k >= 64.0 else (int(k) if k >= 1.0 else 1)
+
+
+def fused_stage(stage, anchor, w, x, base, slot):
+    """sin/cos of w x in the fused analytic flavour: a full evaluation when this step re-anchors the argument (first
+    stage only), else one contracted advance from the anchor; beyond the advance's range: in full (a first stage
+    re-anchors)."""
+    if stage == 0 and anchor:
+        a = w * x
+        sn, cs = rep_sincos(a)
+        base[slot] = (a, sn, cs)
+        return sn, cs
+    a0, s0, c0 = base[slot]
+    d = _fma(w, x, -a0)
+    if abs(d) <= REP_SHIFT_MAX:
+        return rep_shift_fused(s0, c0, d)
+    a = w * x
+    sn, cs = rep_sincos(a)
+    if stage == 0:
+        base[slot] = (a, sn, cs)
+    return sn, cs
+
+
 def rep_stage(stage, a, base, slot):
     """sin/cos of a at RK4 stage 0..3: stage 0 evaluates and remembers, the others advance from it."""
     if stage == 0:
@@ -101,7 +141,9 @@ def rep_stage(stage, a, base, slot):
 class SinProd:
     """c = 1 + A sin(wx x) sin(wy y);  grad c = [gx cos sin, gy sin cos].
     trig = "libm": math.sin/cos (as the reference calls its own); trig = "rep": the reproducible flavour above, the
-    sequence the HIP kernels evaluate (stages of an RK4 step through `hamilton_staged`)."""
+    sequence the HIP kernels' exact flavour evaluates (stages of an RK4 step through `hamilton_staged`); trig = "fused":
+    the kernels' default -- Hamilton (@fastmath in the reference, NonObstacle.jl:1) with its multiply-adds contracted,
+    sin/cos anchors shared by consecutive steps (`hamilton_fused`, `_rk4_fused`)."""
 
     def __init__(self, A, wx, wy, gx, gy, trig="libm"):
         self.A, self.wx, self.wy, self.gx, self.gy, self.trig = A, wx, wy, gx, gy, trig
@@ -115,6 +157,18 @@ class SinProd:
         s2 = speed * speed
         return [s2 * X[2], s2 * X[3], ((-tau) * g[0]) * speed, ((-tau) * g[1]) * speed], 0
 
+    def hamilton_fused(self, X, stage, anchor, base):
+        sx, cx = fused_stage(stage, anchor & 1, self.wx, X[0], base, 0)
+        sy, cy = fused_stage(stage, anchor & 2, self.wy, X[1], base, 1)
+        speed = _fma(self.A * sx, sy, 1.0)
+        tau = _fma(X[3], X[3], X[2] * X[2])
+        s2, w = speed * speed, speed * tau
+        return [s2 * X[2], s2 * X[3], ((-self.gx) * w) * (cx * sy), ((-self.gy) * w) * (sx * cy)]
+
+    def anchor_periods(self, dt):
+        cmax = 1 + abs(self.A)
+        return [anchor_period(self.wx, dt, cmax), anchor_period(self.wy, dt, cmax)]
+
     @staticmethod
     def smooth_demo():  # NonObstacleDemo.jl:12,23
         return SinProd(0.3, 1.5 * pi, 1.5 * pi, 0.45 * pi, 0.45 * pi)
@@ -124,7 +178,7 @@ class SinProd:
         return SinProd(0.2, 2 * pi, pi, 2 * (0.2 * pi), 0.2 * pi)
 
     def c(self, x, y):
-        if self.trig == "rep":
+        if self.trig in ("rep", "fused"):
             return 1 + self.A * rep_sincos(self.wx * x)[0] * rep_sincos(self.wy * y)[0]
         return 1 + self.A * sin(self.wx * x) * sin(self.wy * y)
 
@@ -295,7 +349,7 @@ def init_states(med, ns, nd, dir_lo=0.0, dir_hi=pi, src_begin=0, src_end=None):
     source = linspace(0.0, 2 * pi, ns + 1)[:ns]
     direct = linspace(dir_lo, dir_hi, nd + 2)[1:nd + 1]
     rows = []
-    rep = getattr(med, "trig", "libm") == "rep"
+    rep = getattr(med, "trig", "libm") in ("rep", "fused")
     for i in range(src_begin, src_end):
         sx, sy = cos(source[i]), sin(source[i])
         if rep:
@@ -308,8 +362,32 @@ def init_states(med, ns, nd, dir_lo=0.0, dir_hi=pi, src_begin=0, src_end=None):
     return rows
 
 
-def _rk4_kdt(med, X, dt):  # NonObstacle.jl:72-76
+def _rk4_fused(med, X, dt, state):
+    """One RK4 step of the fused analytic flavour: Y = fma(H, dt/2, X), Xn = fma(sum, dt RN(1/6), X) (the gridded fused
+    flavour's combination); `state` carries the ray's sin/cos anchors and countdowns from step to step."""
+    if not state:
+        state.update(base={}, acnt=[0, 0], K=med.anchor_periods(dt))
+    anchor = 0
+    for k in range(2):
+        if state["acnt"][k] == 0:
+            anchor |= 1 << k
+            state["acnt"][k] = state["K"][k]
+        state["acnt"][k] -= 1
+    hdt, dt6 = 0.5 * dt, dt * 0.16666666666666666
+    H = med.hamilton_fused(X, 0, anchor, state["base"])
+    acc = list(H)
+    H = med.hamilton_fused([_fma(H[k], hdt, X[k]) for k in range(4)], 1, anchor, state["base"])
+    acc = [_fma(2.0, H[k], acc[k]) for k in range(4)]
+    H = med.hamilton_fused([_fma(H[k], hdt, X[k]) for k in range(4)], 2, anchor, state["base"])
+    acc = [_fma(2.0, H[k], acc[k]) for k in range(4)]
+    H = med.hamilton_fused([_fma(H[k], dt, X[k]) for k in range(4)], 3, anchor, state["base"])
+    return [_fma(acc[k] + H[k], dt6, X[k]) for k in range(4)], 0
+
+
+def _rk4_kdt(med, X, dt, state=None):  # NonObstacle.jl:72-76
     oob = 0
+    if getattr(med, "trig", "libm") == "fused":
+        return _rk4_fused(med, X, dt, state)
     if getattr(med, "trig", "libm") == "rep" and hasattr(med, "hamilton_staged"):
         base, stage = {}, iter(range(4))
         rhs = lambda Y: med.hamilton_staged(Y, next(stage), base)
@@ -337,6 +415,7 @@ def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000, paths=Non
         res = [(X[0], X[1])]
         t = 0
         rfl = st = steps = nref = 0
+        state = {}                                       # the fused analytic flavour's per-ray sin/cos anchors
         while True:
             if steps >= max_steps:
                 st |= ST_STEP_CAP
@@ -344,7 +423,7 @@ def shoot(med, rows, dt, obstacle=None, time_unit=0, max_steps=100000, paths=Non
             if obstacle is not None and obstacle.ob(X[0], X[1]) > 0:
                 rfl = 0
             prev = X
-            X, o = _rk4_kdt(med, X, dt)
+            X, o = _rk4_kdt(med, X, dt, state)
             if o:
                 st |= ST_OOB
             steps += 1

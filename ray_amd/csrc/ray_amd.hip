@@ -88,6 +88,8 @@ struct ShootArgs {
     int ob_kind;
     double ob_r0, ob_rho, ob_rho_n;   // circle: r0; trefoil: R, rho of the level set, rho of the normal
     double ob_far2;                   // x^2 + y^2 above this: outside the obstacle for certain (ob > 0 without evaluating it)
+    double ob_in2;                    // circle: the largest s = x^2 + y^2 with fl(sqrt(s)) <= r0, i.e. ob <= 0  <=>  s <= ob_in2
+    int anchor_k[kRadialMax];         // kFused analytic media: steps one full sin/cos evaluation anchors, per argument
     // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
     int init;
     int nd;
@@ -258,6 +260,8 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
     unsigned long long lm = __builtin_amdgcn_ballot_w64(active);
     OobMax o = 0;
     RecState rs;
+    TrigBase tb;                                            // analytic media: the sin/cos anchors (ray_device.h)
+    int acnt[kRadialMax] = {0, 0, 0, 0};                    // wave-uniform countdowns to the next full evaluation
     // ob(X) at the top of a step (Obstacle.jl:28) is ob of the point the previous step tested (:69), or of
     // the reflection point R whose value ended the bisection (:79): evaluated once, carried
     double obv = (OB != kObNone) ? ob_val<OB>(a, X[0], X[1]) : 0.0;
@@ -265,7 +269,15 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
         const bool was = active;
         if (OB != kObNone) { if (active && obv > 0) rfl = 0; }                             // Obstacle.jl:28-30
         double Xn[4];
-        rk4<MED, AR, 0>(a.med, acc, X, Xn, dt, lm, o, rs);
+        unsigned anchor = 0;
+        if (MED != kGrid && AR == kFused) {
+#pragma unroll
+            for (int k = 0; k < (MED == kSinProd ? 2 : kRadialMax); ++k) {
+                if (acnt[k] == 0) { anchor |= 1u << k; acnt[k] = a.anchor_k[k]; }
+                --acnt[k];
+            }
+        }
+        rk4<MED, AR, 0>(a.med, acc, X, Xn, dt, lm, o, rs, tb, anchor);
         ++it;
         tw = a.time_unit ? tw + 1 : tw + dt;                // Obstacle.jl:39 / NonObstacle.jl:77
         // norm(X[1:2]) >= 1  <=>  x^2+y^2 >= 1 for a correctly rounded sqrt  (NonObstacle.jl:78)
@@ -281,7 +293,10 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
                 // only the sign of ob is ever used here (:28, :69): beyond the trefoil's largest radius it is known
                 // without the square root and the division (a wave of a coherent fan is mostly all inside or all
                 // outside: -5.3 % kernel time; for the circle the test costs more than the square root it saves)
+                // The circle's ob = fl(sqrt(s)) - r0 has the sign of s - ob_in2 exactly (the rounded root is monotone in s;
+                // the host derives the threshold): no square root per step.
                 if (OB == kObTrefoil && s > a.ob_far2) obv = 1.0;
+                else if (OB == kObCircle) obv = s > a.ob_in2 ? 1.0 : 0.0;
                 else obv = ob_val<OB>(a, Xn[0], Xn[1]);
                 if (obv <= 0 && rfl == 0) {                                      // Obstacle.jl:69-91
                     double lo = 0, hi = 1, mid = 0.5, E[4], e;
@@ -447,7 +462,8 @@ __global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
         double Xn[4];
         OobMax o = 0;
         const bool was = active;
-        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o, rs);
+        TrigBase tb;                                         // (analytic media only: unused on the grid)
+        rk4<kGrid, AR, 1>(a.med, acc, X, Xn, dtl, __builtin_amdgcn_ballot_w64(active), o, rs, tb, 0u);
         ++it;
         const double s = Xn[0] * Xn[0] + Xn[1] * Xn[1];
         if (active) {
@@ -1163,6 +1179,24 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
         const double far = (std::fabs(a.ob_r0) + std::fabs(a.ob_rho)) * (1 + 1e-9);
         a.ob_far2 = far * far * (1 + 1e-9);
     }
+    a.ob_in2 = 0.0;
+    if (obk == RAY_OB_CIRCLE) {
+        // largest double s with fl(sqrt(s)) <= r0 (host sqrt: correctly rounded, as the device's is): start at r0^2, walk
+        double t = a.ob_r0 * a.ob_r0;
+        while (std::sqrt(t) > a.ob_r0) t = std::nextafter(t, 0.0);
+        while (std::sqrt(std::nextafter(t, INFINITY)) <= a.ob_r0) t = std::nextafter(t, INFINITY);
+        a.ob_in2 = t;
+    }
+    for (int k = 0; k < kRadialMax; ++k) a.anchor_k[k] = 1;
+    if (med->kind == kSinProd) {
+        const double cmax = 1 + std::fabs(med->sp.A);
+        a.anchor_k[0] = trig::anchor_period(med->sp.wx, a.dt, cmax);
+        a.anchor_k[1] = trig::anchor_period(med->sp.wy, a.dt, cmax);
+    } else if (med->kind == kRadial) {
+        double cmax = 1;
+        for (int k = 0; k < med->rd.K; ++k) cmax += std::fabs(med->rd.a[k]);
+        for (int k = 0; k < med->rd.K; ++k) a.anchor_k[k] = trig::anchor_period(3.141592653589793, a.dt, cmax);
+    }
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
@@ -1201,12 +1235,18 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
         if (med->kind == kGrid) {
             if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 1, lds);
             else RAY_LAUNCH_BY_OB(kGrid, kExact, 1, lds);
-        } else if (med->kind == kRadial) RAY_LAUNCH_BY_OB(kRadial, kExact, 1, 0);
+        } else if (med->kind == kRadial) {
+            if (fused) RAY_LAUNCH_BY_OB(kRadial, kFused, 1, 0);
+            else RAY_LAUNCH_BY_OB(kRadial, kExact, 1, 0);
+        } else if (fused) RAY_LAUNCH_BY_OB(kSinProd, kFused, 1, 0);
         else RAY_LAUNCH_BY_OB(kSinProd, kExact, 1, 0);
     } else if (med->kind == kGrid) {
         if (fused) RAY_LAUNCH_BY_OB(kGrid, kFused, 0, lds);
         else RAY_LAUNCH_BY_OB(kGrid, kExact, 0, lds);
-    } else if (med->kind == kRadial) RAY_LAUNCH_BY_OB(kRadial, kExact, 0, 0);
+    } else if (med->kind == kRadial) {
+        if (fused) RAY_LAUNCH_BY_OB(kRadial, kFused, 0, 0);
+        else RAY_LAUNCH_BY_OB(kRadial, kExact, 0, 0);
+    } else if (fused) RAY_LAUNCH_BY_OB(kSinProd, kFused, 0, 0);
     else RAY_LAUNCH_BY_OB(kSinProd, kExact, 0, 0);
 #undef RAY_LAUNCH_BY_OB
 #undef RAY_LAUNCH_SHOOT

@@ -518,33 +518,57 @@ __device__ __forceinline__ double sin_rep(double a)
     return sn;
 }
 
-// sin/cos of the step's first stage, from which the other three stages are advanced (trig::shift): their arguments
-// differ from the first stage's by w * (Y - X) = O(w dt c).  The difference of the two rounded arguments is taken
-// exactly as computed, so each stage still evaluates sin/cos of its own argument w * Y, to 1 ulp of 1.
+// sin/cos of an ANCHOR evaluation, from which the stages are advanced (trig::shift): their arguments differ from the
+// anchor's by w * (Y - X_anchor) = O(w dt c).  The difference of the two arguments is taken as computed, so each stage
+// still evaluates sin/cos of its own argument w * Y, to 1 ulp of 1, one advance away from a full evaluation.
+//   kExact: the anchor is the step's own first stage (every step evaluates it in full).
+//   kFused: an anchor serves K consecutive steps (trig::anchor_period; `anchor` = the wave-uniform "this step re-anchors"
+//           bit of the argument), the difference is one fma, the advance is trig::shift_fused.  A lane whose argument
+//           has moved beyond kShiftMax evaluates in full and -- at a first stage -- re-anchors itself.
 struct TrigBase {
     double a[kRadialMax], s[kRadialMax], c[kRadialMax];   // per argument: x and y of the sin-product, r_k of the radial sum
 };
-template <int STAGE>
-__device__ __forceinline__ void sincos_stage(double a, double &base_a, double &base_s, double &base_c, double &sn, double &cs)
+template <int STAGE, int AR>
+__device__ __forceinline__ void sincos_stage(double w, double x, bool anchor, double &base_a, double &base_s, double &base_c,
+                                             double &sn, double &cs)
 {
-    if (STAGE == 0) {
+    if (STAGE == 0 && (AR == kExact || anchor)) {
+        const double a = w * x;
         if (trig::in_range(a)) trig::sincos_bounded(a, sn, cs);
         else { const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y; }
         base_a = a; base_s = sn; base_c = cs;
     } else {
-        const double d = a - base_a;
-        if (__builtin_fabs(d) <= trig::kShiftMax) trig::shift(base_s, base_c, d, sn, cs);
-        else { const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y; }
+        const double d = (AR == kFused) ? __builtin_fma(w, x, -base_a) : w * x - base_a;
+        if (__builtin_fabs(d) <= trig::kShiftMax) {
+            if (AR == kFused) trig::shift_fused(base_s, base_c, d, sn, cs);
+            else trig::shift(base_s, base_c, d, sn, cs);
+        } else {
+            const double a = w * x;
+            const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y;
+            if (STAGE == 0) { base_a = a; base_s = sn; base_c = cs; }
+        }
     }
 }
 
 // a1: Hamilton with the analytic sin-product medium                  NonObstacle.jl:1-4
-template <int STAGE>
-__device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4], TrigBase &tb)
+// kFused (the reference's Hamilton is @fastmath): speed = fma(A sx, sy, 1), tau = fma(py, py, px px),
+// H[2:3] = (-g cos sin) * (speed tau) with the sign folded into the constant.
+template <int STAGE, int AR>
+__device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4], TrigBase &tb, unsigned anchor)
 {
     double sx, cx, sy, cy;
-    sincos_stage<STAGE>(s.wx * X[0], tb.a[0], tb.s[0], tb.c[0], sx, cx);
-    sincos_stage<STAGE>(s.wy * X[1], tb.a[1], tb.s[1], tb.c[1], sy, cy);
+    sincos_stage<STAGE, AR>(s.wx, X[0], anchor & 1u, tb.a[0], tb.s[0], tb.c[0], sx, cx);
+    sincos_stage<STAGE, AR>(s.wy, X[1], anchor & 2u, tb.a[1], tb.s[1], tb.c[1], sy, cy);
+    if (AR == kFused) {
+        const double speed = __builtin_fma(s.A * sx, sy, 1.0);
+        const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
+        const double s2 = speed * speed, w = speed * tau;
+        H[0] = s2 * X[2];
+        H[1] = s2 * X[3];
+        H[2] = ((-s.gx) * w) * (cx * sy);
+        H[3] = ((-s.gy) * w) * (sx * cy);
+        return;
+    }
     const double speed = 1 + s.A * sx * sy;
     const double g0 = s.gx * (cx * sy);
     const double g1 = s.gy * (sx * cy);
@@ -563,8 +587,9 @@ __device__ __forceinline__ double speed_sinprod(const SinProdDev &s, double x, d
 // a1 with the commented alternate media (NonObstacleDemo.jl:7-11,15-22; ObstacleDemo.jl:9-11,15-17), as written:
 //   c      = 1.0 + a1 * sin(pi * r1) + a2 * sin(pi * r2) + ...             r_k = sqrt((x-x_k)^2 + (y-y_k)^2)
 //   grad c = a1 * pi * cos(pi * r1)/r1 * [(x-x1), (y-y1)] + ...
-template <int STAGE>
-__device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4], double H[4], TrigBase &tb)
+// kFused: the sums as fma chains, r^2 = fma(dy, dy, dx dx), tau and H[2:3] as in rhs_sinprod; the division stays one.
+template <int STAGE, int AR>
+__device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4], double H[4], TrigBase &tb, unsigned anchor)
 {
     constexpr double kPi = 3.141592653589793;
     double speed = 1.0, g0 = 0, g1 = 0;
@@ -572,16 +597,30 @@ __device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4
     for (int k = 0; k < kRadialMax; ++k)
         if (k < rd.K) {
             const double dx = X[0] - rd.x[k], dy = X[1] - rd.y[k];
-            const double r = __builtin_sqrt(dx * dx + dy * dy);
+            const double r = __builtin_sqrt(AR == kFused ? __builtin_fma(dy, dy, dx * dx) : dx * dx + dy * dy);
             double sn, cs;
-            sincos_stage<STAGE>(kPi * r, tb.a[k], tb.s[k], tb.c[k], sn, cs);
-            speed = speed + rd.a[k] * sn;
+            sincos_stage<STAGE, AR>(kPi, r, anchor & (1u << k), tb.a[k], tb.s[k], tb.c[k], sn, cs);
             const double f = ((rd.a[k] * kPi) * cs) / r;
-            if (k == 0) { g0 = f * dx; g1 = f * dy; }
-            else { g0 = g0 + f * dx; g1 = g1 + f * dy; }
+            if (AR == kFused) {
+                speed = __builtin_fma(rd.a[k], sn, speed);
+                g0 = __builtin_fma(f, dx, g0); g1 = __builtin_fma(f, dy, g1);
+            } else {
+                speed = speed + rd.a[k] * sn;
+                if (k == 0) { g0 = f * dx; g1 = f * dy; }
+                else { g0 = g0 + f * dx; g1 = g1 + f * dy; }
+            }
         }
-    const double tau = X[2] * X[2] + X[3] * X[3];
     const double s2 = speed * speed;
+    if (AR == kFused) {
+        const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
+        const double w = speed * tau;
+        H[0] = s2 * X[2];
+        H[1] = s2 * X[3];
+        H[2] = (-g0) * w;
+        H[3] = (-g1) * w;
+        return;
+    }
+    const double tau = X[2] * X[2] + X[3] * X[3];
     H[0] = s2 * X[2];
     H[1] = s2 * X[3];
     H[2] = ((-tau) * g0) * speed;
@@ -606,11 +645,11 @@ struct MediumDev {
 
 template <int MED, int AR, int MODE = kFetch, int STAGE = 0>
 __device__ __forceinline__ void rhs(const MediumDev &m, const GridAcc &pt, const double X[4], double H[4], OobMax &oob,
-                                    unsigned long long lm, RecState &rs, TrigBase &tb)
+                                    unsigned long long lm, RecState &rs, TrigBase &tb, unsigned anchor)
 {
     if (MED == kGrid) rhs_grid<AR, MODE>(m.g, pt, X, H, oob, lm, rs);
-    else if (MED == kRadial) rhs_radial<STAGE>(m.rd, X, H, tb);
-    else rhs_sinprod<STAGE>(m.sp, X, H, tb);
+    else if (MED == kRadial) rhs_radial<STAGE, AR>(m.rd, X, H, tb, anchor);
+    else rhs_sinprod<STAGE, AR>(m.sp, X, H, tb, anchor);
 }
 
 // fma with a destination of its own (v_fma_f64): the stage update Y = X + H*hdt must leave X alive, and
@@ -626,51 +665,52 @@ __device__ __forceinline__ double fma_vop3(double a, double b, double c)
 // FORM 0 = a6/a7: k = H*dt; X + k1/2; (k1+2k2+2k3+k4)/6.0         NonObstacle.jl:72-76
 // FORM 1 = a8/a9: k = H;    X + k/2*dt; (k1+2k2+2k3+k4)*dt/6.0    NonObstacle.jl:161-164,171
 // kFused (both forms, they are the same formula): Y = fma(H, dt/2, X), Xn = fma(sum, dt*RN(1/6), X)
+// `tb`, `anchor`: analytic media only -- the anchors of the sin/cos advances (they outlive the step in kFused) and the
+// wave-uniform bit mask of the arguments that re-anchor in this step (sincos_stage).
 template <int MED, int AR, int FORM>
 __device__ __forceinline__ void rk4(const MediumDev &m, const GridAcc &pt, const double X[4], double Xn[4], double dt,
-                                    unsigned long long lm, OobMax &oob, RecState &rs)
+                                    unsigned long long lm, OobMax &oob, RecState &rs, TrigBase &tb, unsigned anchor)
 {
     double H[4], Y[4], acc[4];
-    TrigBase tb;
-    if (AR == kFused && MED == kGrid) {
+    if (AR == kFused) {
         const double hdt = 0.5 * dt, dt6 = dt * 0.16666666666666666;
-        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], hdt, X[k]); }
-        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = fma_vop3(H[k], dt, X[k]); }
-        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = __builtin_fma(acc[k] + H[k], dt6, X[k]);
     } else if (FORM == 0) {
-        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = kk; Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = __builtin_fma(kk, 0.5, X[k]); }
-        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; acc[k] = __builtin_fma(2.0, kk, acc[k]); Y[k] = X[k] + kk; }
-        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { double kk = H[k] * dt; Xn[k] = X[k] + div6(acc[k] + kk); }
     } else {
         const double hdt = 0.5 * dt;              // (H/2)*dt == RN(H*(dt/2)): halving is exact
-        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 0>(m, pt, X, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 1>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * hdt; }
-        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kLookup, 2>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acc[k] = __builtin_fma(2.0, H[k], acc[k]); Y[k] = X[k] + H[k] * dt; }
-        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb);
+        rhs<MED, AR, kFetch, 3>(m, pt, Y, H, oob, lm, rs, tb, anchor);
 #pragma unroll
         for (int k = 0; k < 4; ++k) Xn[k] = X[k] + div6((acc[k] + H[k]) * dt);
     }

@@ -43,6 +43,10 @@ def assert_rays(m, info, ref_m, ref_st, ref_ns, ref_nr=None, exact=False, bisect
     if ref_nr is not None:
         assert np.array_equal(info["nreflect"], ref_nr)
     if exact:
+        if not np.array_equal(m, ref_m):
+            bad = np.argwhere(m != ref_m)
+            print("entries that differ: %d, columns %s, first rows %s, max |diff| %.3e"
+                  % (len(bad), np.unique(bad[:, 1]).tolist(), np.unique(bad[:, 0])[:12].tolist(), np.nanmax(np.abs(m - ref_m))))
         assert np.array_equal(m, ref_m)
     else:
         assert rel_err(m[:, 0:8], ref_m[:, 0:8]) <= RTOL
@@ -161,8 +165,11 @@ def test_grid_golden(ctx, arith):
 
 @pytest.mark.parametrize("params,ns,nd,dt", [("SMOOTH_DEMO", 100, 100, 1e-2), ("SMOOTH_DEMO", 7, 333, 5e-3),
                                              ("OBSTACLE_DEMO", 13, 64, 2e-2)])
-def test_scatter_analytic_vs_oracle(ctx, orc, params, ns, nd, dt):
-    """config 1 (NonObstacleDemo.jl as shipped: 100x100, dt=1e-2) and ragged sizes."""
+def test_scatter_analytic_vs_oracle(ctx, orc, arith, params, ns, nd, dt):
+    """config 1 (NonObstacleDemo.jl as shipped: 100x100, dt=1e-2) and ragged sizes; both arithmetic flavours of the
+    analytic right-hand side (exact: Hamilton as written; fused, the default: contracted, sin/cos anchors shared by
+    consecutive steps), each bit for bit against the oracle's restatement of it and within RTOL, with identical events,
+    of the as-written host-libm oracle."""
     import ray_amd
     prm = getattr(orc, params)
     ref, st, nst, nrf = orc.scatter_relation(prm, ns, nd, dt, nthreads=8)
@@ -170,12 +177,12 @@ def test_scatter_analytic_vs_oracle(ctx, orc, params, ns, nd, dt):
     assert_rays(m, info, ref, st, nst, nrf)
     assert np.all(st == orc.ST_EXITED)
     # the oracle's reproducible sin/cos flavour restates the kernels' evaluation: every bit
-    ref, st, nst, nrf = orc.scatter_relation(prm, ns, nd, dt, nthreads=8, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(prm, ns, nd, dt, nthreads=8, trig=1, arith=arith)
     assert_rays(m, info, ref, st, nst, nrf, exact=True)
 
 
 @pytest.mark.parametrize("dt", [1e-2, 5e-3])
-def test_scatter_obstacle_shipped_config(ctx, orc, dt):
+def test_scatter_obstacle_shipped_config(ctx, orc, arith, dt):
     """config 3 (ObstacleDemo.jl:39-44): 50 x 300 rays, dt = 1e-2, circle r0 = 0.3, t in steps; and the same sweep at
     accurateTimeStep = 5e-3 (ObstacleDemo.jl:305-307)."""
     import ray_amd
@@ -185,7 +192,7 @@ def test_scatter_obstacle_shipped_config(ctx, orc, dt):
                                               ns, nd, dt, ctx=ctx, info=True)
     assert nrf.sum() > 1000
     assert_rays(m, info, ref, st, nst, nrf)
-    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=0.3, time_unit=1, nthreads=8, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=0.3, time_unit=1, nthreads=8, trig=1, arith=arith)
     assert_rays(m, info, ref, st, nst, nrf, exact=True)
 
 
@@ -204,6 +211,15 @@ def test_scatter_reproducible_trig_golden(ctx):
     """the committed fixtures of the Python restatement's reproducible sin/cos flavour (exact-rational fma): the
     analytic smooth demo and the obstacle demo around the trefoil, bit for bit and event for event."""
     import ray_amd
+    ctx.set_arith(ray_amd.ARITH_EXACT)              # the fixtures restate Hamilton as written (one full sin/cos per step)
+    try:
+        _reproducible_trig_golden(ctx)
+    finally:
+        ctx.set_arith(ray_amd.ARITH_FUSED)
+
+
+def _reproducible_trig_golden(ctx):
+    import ray_amd
     g = golden("scatter_smooth_rep_ns8_nd16.npz")
     m, info = ray_amd.ScatterRelation(ray_amd.SinProd(*g["params"]), None, int(g["ns"]), int(g["nd"]),
                                       float(g["dt"]), (0.0, math.pi), ctx=ctx, info=True)
@@ -215,7 +231,22 @@ def test_scatter_reproducible_trig_golden(ctx):
     assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
 
 
-def test_scatter_trefoil_vs_oracle(ctx, orc):
+def test_scatter_fused_golden(ctx):
+    """the committed fixtures of the Python restatement's FUSED analytic flavour (the kernels' default: contracted
+    Hamilton, shared sin/cos anchors; exact-rational fma): smooth demo and obstacle demo around the circle, bit for bit."""
+    import ray_amd
+    g = golden("scatter_smooth_fused_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelation(ray_amd.SinProd(*g["params"]), None, int(g["ns"]), int(g["nd"]),
+                                      float(g["dt"]), (0.0, math.pi), ctx=ctx, info=True)
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
+    g = golden("scatter_obstacle_fused_ns8_nd16.npz")
+    m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd(*g["params"]), None, ray_amd.Circle(float(g["r0"])), None,
+                                              int(g["ns"]), int(g["nd"]), float(g["dt"]), ctx=ctx, info=True)
+    assert info["nreflect"].sum() > 10
+    assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"], exact=True)
+
+
+def test_scatter_trefoil_vs_oracle(ctx, orc, arith):
     """BASELINE config 3's cavity: ObstacleDemo.jl's sweep (50 x 300, dt = 1e-2, t in steps) around the trefoil
     in the analytic medium, against the oracle's identity flavour (the kernels' own evaluation of the level set).
     With the oracle's reproducible sin/cos flavour (the kernels' own evaluation of the medium) every ray agrees in
@@ -226,11 +257,13 @@ def test_scatter_trefoil_vs_oracle(ctx, orc):
     tf = ("trefoil", 0.4, 0.3, 0.2, 1)
     m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ray_amd.Trefoil.demo(), None,
                                               ns, nd, dt, ctx=ctx, info=True)
-    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=tf, time_unit=1, nthreads=8, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=tf, time_unit=1, nthreads=8, trig=1, arith=arith)
     assert nrf.sum() > 1000 and nrf.max() >= 2
     assert_rays(m, info, ref, st, nst, nrf, exact=True)
     ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=tf, time_unit=1, nthreads=8)
-    assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 2e-3)
+    # (measured: 1.1e-3 of the rays in the exact flavour, 3e-3 in the fused one, whose trajectories sit ~1e-12 instead of
+    # ~1e-13 from the libm ones: more of the signs taken ON the boundary come out differently)
+    assert_rays_up_to_marginal_events(m, info, ref, st, nst, nrf, 2e-3 if arith == 0 else 6e-3)
 
 
 def test_grid_trefoil_identity_golden(ctx, orc, arith):
@@ -297,14 +330,14 @@ def test_scatter_radial_golden(ctx, name):
     assert_rays(m, info, g["m"], g["status"], g["nsteps"], g["nreflect"])
 
 
-def test_scatter_radial_vs_oracle(ctx, orc):
+def test_scatter_radial_vs_oracle(ctx, orc, arith):
     import ray_amd
     ns, nd, dt = 40, 96, 1e-2
     ref, st, nst, nrf = orc.scatter_relation(orc.SMOOTH_ALT, ns, nd, dt, nthreads=8)
     m, info = ray_amd.ScatterRelation(ray_amd.RadialSineSum.smooth_alt(), None, ns, nd, dt, ctx=ctx, info=True)
     assert_rays(m, info, ref, st, nst, nrf)
     assert np.all(st == orc.ST_EXITED)
-    ref, st, nst, nrf = orc.scatter_relation(orc.SMOOTH_ALT, ns, nd, dt, nthreads=8, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(orc.SMOOTH_ALT, ns, nd, dt, nthreads=8, trig=1, arith=arith)
     assert_rays(m, info, ref, st, nst, nrf, exact=True)
     with pytest.raises(ray_amd.RayError):
         ray_amd.ScatterRelation(ray_amd.RadialSineSum([(0.1, 0, 0)] * 5), None, 4, 4, dt, ctx=ctx)
@@ -489,7 +522,7 @@ def test_misfit_vs_oracle(ctx, orc, num):
 
 # ---- size-independent properties at the BASELINE config-2 size (2048 x 2048 rays, 512^2 grid) --------
 @pytest.mark.parametrize("shape", ["circle", "trefoil"])
-def test_full_size_analytic_obstacle_every_ray(ctx, orc, shape):
+def test_full_size_analytic_obstacle_every_ray(ctx, orc, arith, shape):
     """BASELINE config 3 at the timing size: ObstacleDemo's analytic medium around the circle and around
     the trefoil with its cavities, 2048 x 2048 rays, dt = 1e-2, t in steps -- EVERY ray against the oracle's
     reproducible-sin/cos (and identity) flavour, bit for bit and event for event (0.84 / 2.0 million reflections;
@@ -498,18 +531,18 @@ def test_full_size_analytic_obstacle_every_ray(ctx, orc, shape):
     ns, nd, dt = 2048, 2048, 1e-2
     ob, orc_ob = (ray_amd.Circle(0.3), 0.3) if shape == "circle" else (ray_amd.Trefoil.demo(), ("trefoil", 0.4, 0.3, 0.2, 1))
     m, info = ray_amd.ScatterRelationObstacle(ray_amd.SinProd.obstacle_demo(), None, ob, None, ns, nd, dt, ctx=ctx, info=True)
-    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=orc_ob, time_unit=1, nthreads=16, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=orc_ob, time_unit=1, nthreads=16, trig=1, arith=arith)
     assert nrf.sum() > 800000 and np.all(st == orc.ST_EXITED)
     assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst) and np.array_equal(info["nreflect"], nrf)
     assert np.array_equal(m, ref)
 
 
-def test_full_size_analytic_smooth_every_ray(ctx, orc):
+def test_full_size_analytic_smooth_every_ray(ctx, orc, arith):
     """NonObstacleDemo's analytic medium (config 1's) at the 2048 x 2048 size: every ray, every bit, from (ns, nd)."""
     import ray_amd
     ns, nd, dt = 2048, 2048, 1e-2
     m, info = ray_amd.ScatterRelation(ray_amd.SinProd.smooth_demo(), None, ns, nd, dt, ctx=ctx, info=True)
-    ref, st, nst, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, dt, nthreads=16, trig=1)
+    ref, st, nst, _ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, dt, nthreads=16, trig=1, arith=arith)
     assert np.all(st == orc.ST_EXITED)
     assert np.array_equal(info["status"], st) and np.array_equal(info["nsteps"], nst)
     assert np.array_equal(m, ref)
@@ -644,7 +677,10 @@ def test_census_config3_default_vs_host_libm(ctx, orc, shape):
     bad = (info["status"] != st) | (info["nsteps"] != nst) | (info["nreflect"] != nrf)
     print("config 3 (%s) census: %d rays, %d classify differently from the host-libm oracle: rows %s"
           % (shape, st.size, bad.sum(), np.flatnonzero(bad)[:32].tolist()))
-    assert bad.mean() <= (2e-5 if shape == "circle" else 2e-3)
+    # circle: 0 of 4 194 304 measured.  trefoil: 2.9e-3 -- after a reflection the reference re-arms on the sign of ob(R)
+    # with |ob(R)| <= 1e-15 (Obstacle.jl:28-30,77): for a ray whose next step also ends inside the level set (the
+    # cavities) that sign decides between reflecting again and passing, and it is noise below ANY rounding difference
+    assert bad.mean() <= (2e-5 if shape == "circle" else 6e-3)
     ok = ~bad
     assert rel_err(m[ok, 0:8], ref[ok, 0:8]) <= RTOL
     perr = rel_err(m[ok, 0:8], ref[ok, 0:8])
@@ -686,7 +722,7 @@ def test_obstacle_demo_stage_two_draws_the_obstacle(ctx, orc, shape):
     ob, orc_ob = (ray_amd.Circle(0.3), 0.3) if shape == "circle" else (ray_amd.Trefoil.demo(), ("trefoil", 0.4, 0.3, 0.2, 1))
     sp = ray_amd.SinProd.obstacle_demo()
     m, info = ray_amd.ScatterRelationObstacle(sp, None, ob, None, ns, nd, dt, ctx=ctx, info=True)       # :306-307
-    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=orc_ob, time_unit=1, nthreads=8, trig=1)
+    ref, st, nst, nrf = orc.scatter_relation(orc.OBSTACLE_DEMO, ns, nd, dt, obstacle_r0=orc_ob, time_unit=1, nthreads=8, trig=1, arith=1)
     assert_rays(m, info, ref, st, nst, nrf, exact=True)                                             # dt = 5e-3
     cls = ray_amd.classify_rays(m, ns, nd, ctx=ctx)                                                 # :309-310
     ortho_ref, _, _, _ = orc.classify(ref, ns, nd)

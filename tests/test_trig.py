@@ -18,6 +18,9 @@ extern "C" void t_sincos(const double *a, long n, double *s, double *c)
 { for (long i = 0; i < n; ++i) ray::trig::sincos_bounded(a[i], s[i], c[i]); }
 extern "C" void t_shift(const double *s0, const double *c0, const double *d, long n, double *s, double *c)
 { for (long i = 0; i < n; ++i) ray::trig::shift(s0[i], c0[i], d[i], s[i], c[i]); }
+extern "C" void t_shift_fused(const double *s0, const double *c0, const double *d, long n, double *s, double *c)
+{ for (long i = 0; i < n; ++i) ray::trig::shift_fused(s0[i], c0[i], d[i], s[i], c[i]); }
+extern "C" int t_anchor_period(double w, double dt, double cmax) { return ray::trig::anchor_period(w, dt, cmax); }
 """
 
 
@@ -44,6 +47,12 @@ def hdr_sincos(hdr, a):
 def hdr_shift(hdr, s0, c0, d):
     s, c = np.empty_like(d), np.empty_like(d)
     hdr.t_shift(_dp(s0), _dp(c0), _dp(d), C.c_long(d.size), _dp(s), _dp(c))
+    return s, c
+
+
+def hdr_shift_fused(hdr, s0, c0, d):
+    s, c = np.empty_like(d), np.empty_like(d)
+    hdr.t_shift_fused(_dp(s0), _dp(c0), _dp(d), C.c_long(d.size), _dp(s), _dp(c))
     return s, c
 
 
@@ -84,6 +93,33 @@ def test_shift_accuracy(hdr):
     assert float(np.abs(c - np.cos(al)).max()) <= 2.3e-16
 
 
+def test_fused_shift_accuracy_and_restatements(hdr, orc):
+    """the contracted advance of the fused analytic flavour: as accurate as the plain one (one advance from a full
+    evaluation), the C oracle's and the Python restatement's (exact-rational fma) readings equal the header's bit for
+    bit; the anchor period is the same integer in all three."""
+    import ray_oracle as P
+    rng = np.random.default_rng(21)
+    a0 = rng.uniform(-8, 8, 200000)
+    d = rng.uniform(-0.25, 0.25, a0.size)
+    s0, c0 = hdr_sincos(hdr, a0)
+    s, c = hdr_shift_fused(hdr, s0, c0, d)
+    if np.finfo(np.longdouble).nmant >= 63:
+        al = a0.astype(np.longdouble) + d.astype(np.longdouble)
+        assert float(np.abs(s - np.sin(al)).max()) <= 2.3e-16
+        assert float(np.abs(c - np.cos(al)).max()) <= 2.3e-16
+    for i in range(0, 20000):
+        assert orc.rep_shift_fused(float(s0[i]), float(c0[i]), float(d[i])) == (s[i], c[i])
+    for i in range(0, 400):
+        assert P.rep_shift_fused(float(s0[i]), float(c0[i]), float(d[i])) == (s[i], c[i])
+    hdr.t_anchor_period.argtypes = [C.c_double] * 3
+    for w, dt, cmax in [(2 * math.pi, 1e-2, 1.2), (math.pi, 1e-2, 1.2), (1.5 * math.pi, 1e-2, 1.3), (math.pi, 5e-3, 2.1),
+                        (0.0, 1e-2, 1.0), (1e-9, 1e-2, 1.0), (50.0, 1e-1, 2.0), (3.0, 2e-2, 1.25), (float("nan"), 1e-2, 1.0)]:
+        k = hdr.t_anchor_period(w, dt, cmax)
+        assert 1 <= k <= 64 and k == orc.anchor_period(w, dt, cmax)
+        if w == w:
+            assert k == P.anchor_period(w, dt, cmax) if w != 0.0 else k == 64
+
+
 def test_oracle_restatement_equals_header(hdr, orc):
     rng = np.random.default_rng(13)
     a = np.concatenate([rng.uniform(-12, 12, 20000), rng.uniform(-2.6e5, 2.6e5, 2000),
@@ -122,7 +158,11 @@ def test_flavour_stays_on_the_libm_one(orc):
         m1, st1, n1, r1 = orc.scatter_relation(prm, 50, 120, 1e-2, obstacle_r0=ob, time_unit=tu, nthreads=4, trig=1)
         assert np.array_equal(st0, st1) and np.array_equal(n0, n1) and np.array_equal(r0, r1)
         assert np.max(np.abs(m0 - m1) / np.maximum(1.0, np.abs(m0))) <= 1e-10
+        m2, st2, n2, r2 = orc.scatter_relation(prm, 50, 120, 1e-2, obstacle_r0=ob, time_unit=tu, nthreads=4, trig=1, arith=1)
+        assert np.array_equal(st0, st2) and np.array_equal(n0, n2) and np.array_equal(r0, r2)     # the fused flavour too
+        assert np.max(np.abs(m0 - m2) / np.maximum(1.0, np.abs(m0))) <= 1e-10
     m0, st0, n0, _ = orc.scatter_relation(orc.SMOOTH_ALT, 20, 60, 1e-2, nthreads=4)
-    m1, st1, n1, _ = orc.scatter_relation(orc.SMOOTH_ALT, 20, 60, 1e-2, nthreads=4, trig=1)
-    assert np.array_equal(st0, st1) and np.array_equal(n0, n1)
-    assert np.max(np.abs(m0 - m1) / np.maximum(1.0, np.abs(m0))) <= 1e-10
+    for arith in (0, 1):
+        m1, st1, n1, _ = orc.scatter_relation(orc.SMOOTH_ALT, 20, 60, 1e-2, nthreads=4, trig=1, arith=arith)
+        assert np.array_equal(st0, st1) and np.array_equal(n0, n1)
+        assert np.max(np.abs(m0 - m1) / np.maximum(1.0, np.abs(m0))) <= 1e-10
