@@ -89,6 +89,7 @@ struct ShootArgs {
     double ob_r0, ob_rho, ob_rho_n;   // circle: r0; trefoil: R, rho of the level set, rho of the normal
     double ob_far2;                   // x^2 + y^2 above this: outside the obstacle for certain (ob > 0 without evaluating it)
     double ob_in2;                    // circle: the largest s = x^2 + y^2 with fl(sqrt(s)) <= r0, i.e. ob <= 0  <=>  s <= ob_in2
+    double ob_lo2, ob_hi2;            // circle: |fl(sqrt(s)) - r0| <= 1e-15  <=>  ob_lo2 <= s <= ob_hi2 (the reflection bisection's stop)
     int anchor_k[kRadialMax];         // kFused analytic media: steps one full sin/cos evaluation anchors, per argument
     // init == 1: generate the boundary phase-space grid (NonObstacle.jl:55-65)
     int init;
@@ -302,14 +303,34 @@ __global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused
                     double lo = 0, hi = 1, mid = 0.5, E[4], e;
                     int ib = 0;
                     rfl = 1;
-                    lerp4(E, X, Xn, mid);
-                    e = ob_val<OB>(a, E[0], E[1]);
-                    while (__builtin_fabs(e) > 1e-15) {
-                        if (++ib > kBisectCap) { st |= kStBisectCap; break; }
-                        if (e > 0) lo = mid; else hi = mid;
-                        mid = (lo + hi) * 0.5;
+                    if (OB == kObCircle) {
+                        // e = fl(sqrt(sq)) - r0 (an exact difference next to r0): `abs(e) > 1e-15` and `e > 0` (Obstacle.jl:
+                        // 76-79) are comparisons of sq = E1^2 + E2^2 with three doubles the host derived from r0 -- the rounded
+                        // root is monotone in sq -- so the ~50 dependent iterations need no square root (as the exit bisection)
+                        E[0] = (1 - mid) * X[0] + mid * Xn[0];
+                        E[1] = (1 - mid) * X[1] + mid * Xn[1];
+                        double sq = E[0] * E[0] + E[1] * E[1];
+                        while (sq < a.ob_lo2 || sq > a.ob_hi2) {
+                            if (++ib > kBisectCap) { st |= kStBisectCap; break; }
+                            if (sq > a.ob_in2) lo = mid; else hi = mid;
+                            mid = (lo + hi) * 0.5;
+                            E[0] = (1 - mid) * X[0] + mid * Xn[0];
+                            E[1] = (1 - mid) * X[1] + mid * Xn[1];
+                            sq = E[0] * E[0] + E[1] * E[1];
+                        }
+                        E[2] = (1 - mid) * X[2] + mid * Xn[2];
+                        E[3] = (1 - mid) * X[3] + mid * Xn[3];
+                        e = sq > a.ob_in2 ? 1.0 : 0.0;           // only the sign of ob(R) is looked at again (the re-arming test)
+                    } else {
                         lerp4(E, X, Xn, mid);
                         e = ob_val<OB>(a, E[0], E[1]);
+                        while (__builtin_fabs(e) > 1e-15) {
+                            if (++ib > kBisectCap) { st |= kStBisectCap; break; }
+                            if (e > 0) lo = mid; else hi = mid;
+                            mid = (lo + hi) * 0.5;
+                            lerp4(E, X, Xn, mid);
+                            e = ob_val<OB>(a, E[0], E[1]);
+                        }
                     }
                     // n = gradObstacle(R); X[3:4] = (eye(2) - 2*n*n') * R[3:4]   Obstacle.jl:84-85
                     double nx, ny;
@@ -1179,13 +1200,23 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
         const double far = (std::fabs(a.ob_r0) + std::fabs(a.ob_rho)) * (1 + 1e-9);
         a.ob_far2 = far * far * (1 + 1e-9);
     }
-    a.ob_in2 = 0.0;
+    a.ob_in2 = a.ob_lo2 = a.ob_hi2 = 0.0;
     if (obk == RAY_OB_CIRCLE) {
         // largest double s with fl(sqrt(s)) <= r0 (host sqrt: correctly rounded, as the device's is): start at r0^2, walk
         double t = a.ob_r0 * a.ob_r0;
         while (std::sqrt(t) > a.ob_r0) t = std::nextafter(t, 0.0);
         while (std::sqrt(std::nextafter(t, INFINITY)) <= a.ob_r0) t = std::nextafter(t, INFINITY);
         a.ob_in2 = t;
+        // the doubles q next to r0 with |q - r0| <= 1e-15 (the difference of neighbours is exact), then their pre-images
+        double qlo = a.ob_r0, qhi = a.ob_r0;
+        while (std::fabs(std::nextafter(qlo, 0.0) - a.ob_r0) <= 1e-15) qlo = std::nextafter(qlo, 0.0);
+        while (std::fabs(std::nextafter(qhi, INFINITY) - a.ob_r0) <= 1e-15) qhi = std::nextafter(qhi, INFINITY);
+        double lo2 = qlo * qlo, hi2 = qhi * qhi;
+        while (std::sqrt(lo2) >= qlo) lo2 = std::nextafter(lo2, 0.0);         // below the pre-image of qlo ...
+        while (std::sqrt(lo2) < qlo) lo2 = std::nextafter(lo2, INFINITY);     // ... its smallest member
+        while (std::sqrt(hi2) <= qhi) hi2 = std::nextafter(hi2, INFINITY);
+        while (std::sqrt(hi2) > qhi) hi2 = std::nextafter(hi2, 0.0);          // the largest s with fl(sqrt(s)) <= qhi
+        a.ob_lo2 = lo2; a.ob_hi2 = hi2;
     }
     for (int k = 0; k < kRadialMax; ++k) a.anchor_k[k] = 1;
     if (med->kind == kSinProd) {
