@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <mutex>
 #include <dlfcn.h>
 #include <cmath>
@@ -674,6 +676,111 @@ static int fail(int code, const std::string &msg)
         }                                                                                      \
     } while (0)
 
+// ---- host-pointer downloads: page-locked ring + copy workers ------------------------------------------------------
+// What a blocking ccall hands over is pageable memory; a hipMemcpy into it goes through the runtime's own small
+// staging buffers at a third of the PCIe rate, and hipHostRegister of the caller's array is refused for the sandboxed
+// users of some installations (profiles/r2/host_pointer_path.jsonl).  The library therefore owns a ring of page-locked
+// slots (hipHostMalloc): a block of result rows is DMA'd into a slot at the full rate on a copy stream of its own
+// while the next block's kernel runs, and a few host threads copy the slot into the caller's array while the next
+// block's DMA runs.  Threads are created on the first large download of a context and joined when it is destroyed.
+struct CopyPiece { void *dst; const void *src; size_t bytes; };
+class CopyPool {
+public:
+    explicit CopyPool(int n)
+    {
+        for (int k = 0; k < n; ++k) th_.emplace_back([this] { work(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> l(mu_); quit_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    // copies every piece (cut into slices of at most 1 MiB, dealt to the workers and to the caller); returns when done
+    void run(const std::vector<CopyPiece> &pieces)
+    {
+        std::vector<CopyPiece> cut;
+        constexpr size_t kSlice = 1u << 20;
+        for (const CopyPiece &p : pieces)
+            for (size_t o = 0; o < p.bytes; o += kSlice)
+                cut.push_back(CopyPiece{static_cast<char *>(p.dst) + o, static_cast<const char *>(p.src) + o, std::min(kSlice, p.bytes - o)});
+        if (cut.empty()) return;
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            job_ = &cut; next_.store(0); left_ = (int)cut.size(); ++gen_;
+        }
+        cv_.notify_all();
+        drain(cut);
+        std::unique_lock<std::mutex> l(mu_);
+        done_.wait(l, [this] { return left_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void drain(const std::vector<CopyPiece> &cut)
+    {
+        int mine = 0;
+        for (;;) {
+            const size_t k = next_.fetch_add(1);
+            if (k >= cut.size()) break;
+            std::memcpy(cut[k].dst, cut[k].src, cut[k].bytes);
+            ++mine;
+        }
+        if (mine) {
+            std::lock_guard<std::mutex> l(mu_);
+            left_ -= mine;
+            if (left_ == 0) done_.notify_all();
+        }
+    }
+    void work()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::vector<CopyPiece> *job;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return quit_ || (gen_ != seen && job_); });
+                if (quit_) return;
+                seen = gen_;
+                job = job_;
+            }
+            drain(*job);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::vector<CopyPiece> *job_ = nullptr;
+    std::atomic<size_t> next_{0};
+    int left_ = 0;
+    unsigned long gen_ = 0;
+    bool quit_ = false;
+};
+
+struct HostRing {
+    static constexpr int kSlots = 2;
+    void *slot[kSlots] = {};
+    size_t cap = 0;                            // bytes per slot
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t filled[kSlots] = {};            // the DMA into the slot has completed
+    std::vector<hipEvent_t> blk_done;          // block k's kernel has completed (recorded on the compute stream)
+    CopyPool *pool = nullptr;
+    bool refused = false;                      // hipHostMalloc failed once on this context: do not ask again
+    void release()
+    {
+        for (int k = 0; k < kSlots; ++k) {
+            if (slot[k]) (void)hipHostFree(slot[k]);
+            if (filled[k]) (void)hipEventDestroy(filled[k]);
+            slot[k] = nullptr; filled[k] = nullptr;
+        }
+        for (hipEvent_t ev : blk_done) (void)hipEventDestroy(ev);
+        blk_done.clear();
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr; cap = 0;
+        delete pool;
+        pool = nullptr;
+    }
+};
+
 struct InitTables;
 struct ray_ctx {
     int device = 0;
@@ -692,6 +799,7 @@ struct ray_ctx {
     static constexpr int kWs = 24;             // 0..11 the Frechet path, 12..23 staging of the host-pointer entry points
     void *ws[kWs] = {};
     size_t ws_cap[kWs] = {};
+    HostRing ring;                             // page-locked staging of the host-pointer downloads
     bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
     int src_stride = 1;                        // RAY_OPT_SOURCE_STRIDE
     int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
@@ -743,7 +851,7 @@ struct DevBuf {                                // scoped device allocation for h
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T> T *as() { return static_cast<T *>(p); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
 struct BorrowedBuf {                           // same accessors as DevBuf, memory owned by the context
@@ -946,6 +1054,7 @@ int ray_ctx_destroy(ray_ctx *ctx)
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     for (int k = 0; k < ray_ctx::kWs; ++k) if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     for (int k = 0; k < ray_ctx::kPool; ++k) if (ctx->csr_pool[k]) (void)hipFree(ctx->csr_pool[k]);
+    ctx->ring.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return RAY_OK;
@@ -981,6 +1090,9 @@ int ray_ctx_release_workspaces(ray_ctx *ctx)
         if (ctx->ws[k]) { (void)hipFree(ctx->ws[k]); ctx->ws[k] = nullptr; ctx->ws_cap[k] = 0; }
     for (int k = 0; k < ray_ctx::kPool; ++k)
         if (ctx->csr_pool[k]) { (void)hipFree(ctx->csr_pool[k]); ctx->csr_pool[k] = nullptr; ctx->csr_cap[k] = 0; }
+    const bool refused = ctx->ring.refused;
+    ctx->ring.release();
+    ctx->ring.refused = refused;
     return RAY_OK;
 }
 
@@ -1312,6 +1424,23 @@ static int call_sources(const ray_ctx *ctx, const ray_shoot_params *prm)
     return (prm->src_end - prm->src_begin + ctx->src_stride - 1) / ctx->src_stride;
 }
 
+// sources [i0, i0 + cnt) of the call's own sources (local indices: source src_begin + i * stride), rows i0 * nd .. of m
+static int shoot_block(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob, const ray_shoot_params *prm,
+                       const InitTables *tab, double *m_dev, int64_t ld, int i0, int cnt,
+                       int32_t *status, int32_t *nsteps, int32_t *nreflect)
+{
+    const int64_t r0 = (int64_t)i0 * prm->nd;
+    ShootArgs a{};
+    a.init = 1; a.nd = prm->nd; a.nsrc = cnt;
+    a.src = tab->src.as<const double>() + i0; a.src_cos = tab->cs.as<const double>() + i0; a.src_sin = tab->sn.as<const double>() + i0;
+    a.direct = tab->dir.as<const double>();
+    a.half_pi = M_PI * 0.5;
+    a.dt = prm->dt; a.time_unit = prm->time_unit; a.max_steps = prm->max_steps;
+    a.m = m_dev + r0; a.num = (int64_t)cnt * prm->nd; a.ld = ld;
+    a.status = status ? status + r0 : nullptr; a.nsteps = nsteps ? nsteps + r0 : nullptr; a.nreflect = nreflect ? nreflect + r0 : nullptr;
+    return launch_shoot(ctx, med, ob, a);
+}
+
 static int shoot_to_exit_impl(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
                               const ray_shoot_params *prm, double *m_dev, int64_t ld,
                               int32_t *status, int32_t *nsteps, int32_t *nreflect)
@@ -1321,15 +1450,7 @@ static int shoot_to_exit_impl(ray_ctx *ctx, const ray_medium *med, const ray_obs
     InitTables *tab = nullptr;
     int rc = init_tables(ctx, prm, &tab);
     if (rc) return rc;
-    ShootArgs a{};
-    a.init = 1; a.nd = prm->nd; a.nsrc = call_sources(ctx, prm);
-    a.src = tab->src.as<double>(); a.src_cos = tab->cs.as<double>(); a.src_sin = tab->sn.as<double>();
-    a.direct = tab->dir.as<double>();
-    a.half_pi = M_PI * 0.5;
-    a.dt = prm->dt; a.time_unit = prm->time_unit; a.max_steps = prm->max_steps;
-    a.m = m_dev; a.num = num; a.ld = ld;
-    a.status = status; a.nsteps = nsteps; a.nreflect = nreflect;
-    return launch_shoot(ctx, med, ob, a);
+    return shoot_block(ctx, med, ob, prm, tab, m_dev, ld, 0, call_sources(ctx, prm), status, nsteps, nreflect);
 }
 
 int ray_shoot_to_exit_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
@@ -1378,6 +1499,80 @@ struct RayOutBufs {
     }
 };
 
+// the ring's slots (>= bytes each), its copy stream, events and workers; false when page-locked memory is not to be had
+constexpr int kCopyWorkers = 6;
+static bool ring_prepare(ray_ctx *ctx, size_t bytes, int nblocks)
+{
+    HostRing &r = ctx->ring;
+    if (r.refused) return false;
+    hipError_t e = hipSuccess;
+    if (!r.copy_stream) {
+        e = hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking);
+        for (int k = 0; k < HostRing::kSlots && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&r.filled[k], hipEventDisableTiming);
+        if (e == hipSuccess && !r.pool) r.pool = new CopyPool(kCopyWorkers);
+    }
+    while (e == hipSuccess && (int)r.blk_done.size() < nblocks) {
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) r.blk_done.push_back(ev);
+    }
+    if (e == hipSuccess && r.cap < bytes) {
+        for (int k = 0; k < HostRing::kSlots; ++k) {
+            if (r.slot[k]) (void)hipHostFree(r.slot[k]);
+            r.slot[k] = nullptr;
+        }
+        r.cap = 0;
+        for (int k = 0; k < HostRing::kSlots && e == hipSuccess; ++k) e = hipHostMalloc(&r.slot[k], bytes, hipHostMallocDefault);
+        if (e == hipSuccess) r.cap = bytes;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        r.release();
+        r.refused = true;                       // e.g. no page-locked memory for this user: the plain copies still work
+        return false;
+    }
+    return true;
+}
+
+// One block of result rows [r0, r0 + rows): which device arrays go to which host arrays, packed into a ring slot as
+// [column c0 | ... | column 8 | status | nsteps | nreflect] (each `rows` long)
+struct RowBlockIo {
+    const double *dm; int64_t ldd;            // device m (num, 9)
+    double *hm; int64_t ldh;                  // host m
+    int c0;                                   // first column that is copied
+    const int32_t *dint[3]; int32_t *hint[3]; // status / nsteps / nreflect (host pointer null: not wanted)
+    size_t row_bytes() const
+    {
+        size_t b = (size_t)(9 - c0) * 8;
+        for (int k = 0; k < 3; ++k) b += hint[k] ? 4 : 0;
+        return b;
+    }
+};
+static hipError_t ring_enqueue_block(ray_ctx *ctx, const RowBlockIo &io, int slot, int64_t r0, int64_t rows)
+{
+    HostRing &r = ctx->ring;
+    char *dst = static_cast<char *>(r.slot[slot]);
+    hipError_t e = hipSuccess;
+    for (int c = io.c0; c < 9 && e == hipSuccess; ++c, dst += rows * 8)
+        e = hipMemcpyAsync(dst, io.dm + (size_t)c * io.ldd + r0, (size_t)rows * 8, hipMemcpyDeviceToHost, r.copy_stream);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        if (io.hint[k]) {
+            e = hipMemcpyAsync(dst, io.dint[k] + r0, (size_t)rows * 4, hipMemcpyDeviceToHost, r.copy_stream);
+            dst += rows * 4;
+        }
+    if (e == hipSuccess) e = hipEventRecord(r.filled[slot], r.copy_stream);
+    return e;
+}
+static void ring_deliver_block(ray_ctx *ctx, const RowBlockIo &io, int slot, int64_t r0, int64_t rows)
+{
+    const char *src = static_cast<const char *>(ctx->ring.slot[slot]);
+    std::vector<CopyPiece> pieces;
+    for (int c = io.c0; c < 9; ++c, src += rows * 8) pieces.push_back(CopyPiece{io.hm + (size_t)c * io.ldh + r0, src, (size_t)rows * 8});
+    for (int k = 0; k < 3; ++k)
+        if (io.hint[k]) { pieces.push_back(CopyPiece{io.hint[k] + r0, src, (size_t)rows * 4}); src += rows * 4; }
+    ctx->ring.pool->run(pieces);
+}
+
 int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *ob,
                       const ray_shoot_params *prm, double *m_host, int64_t ld,
                       int32_t *status, int32_t *nsteps, int32_t *nreflect)
@@ -1386,18 +1581,61 @@ int ray_shoot_to_exit(ray_ctx *ctx, const ray_medium *med, const ray_obstacle *o
     if (rc) return rc;
     if ((rc = check_med(ctx, med)) || (rc = check_params(prm))) return rc;
     if (!m_host) return fail(RAY_ERR_INVALID, "null m");
-    const int64_t num = (int64_t)call_sources(ctx, prm) * prm->nd;
+    const int nsrc = call_sources(ctx, prm);
+    const int64_t num = (int64_t)nsrc * prm->nd;
     if (ld < num) return fail(RAY_ERR_INVALID, "ld smaller than the number of rows");
     if (num == 0) return RAY_OK;
     WsBuf dm(ctx, kWsM);
     RayOutBufs ob_(ctx);
     HIPCHK(dm.alloc(sizeof(double) * 9 * (size_t)num));
     if ((rc = ob_.alloc(num))) return rc;
-    rc = shoot_to_exit_impl(ctx, med, ob, prm, dm.as<double>(), num, ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
-    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     const int c0 = ctx->skip_init_cols ? 4 : 0;             // RAY_OPT_SKIP_INIT_COLUMNS: columns 5..9 only
-    if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, c0, 9 - c0))) return rc;
-    if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
+    RowBlockIo io{dm.as<double>(), num, m_host, ld, c0,
+                  {ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>()}, {status, nsteps, nreflect}};
+    // Large sweeps go out in blocks of sources through the page-locked ring: block k's DMA overlaps block k+1's kernel
+    // and the host threads' copy of block k-1 into the caller's (pageable) array.  Blocks are whole workgroup rows of
+    // sources (64: the XCD arcs of the launch stay intact) and about 24 MiB of results.
+    constexpr size_t kSlotTarget = 24u << 20, kPipeMin = 8u << 20;
+    int bsrc = (int)std::min<int64_t>(nsrc, std::max<int64_t>(1, (int64_t)(kSlotTarget / io.row_bytes()) / prm->nd));
+    if (bsrc >= 64) bsrc &= ~63;
+    const int nblk = (nsrc + bsrc - 1) / bsrc;
+    const bool piped = (size_t)num * io.row_bytes() >= kPipeMin && nblk >= 2 &&
+                       ring_prepare(ctx, (size_t)bsrc * prm->nd * io.row_bytes(), nblk);
+    if (!piped) {
+        rc = shoot_to_exit_impl(ctx, med, ob, prm, dm.as<double>(), num, ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>());
+        if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+        if ((rc = copy_cols_d2h(ctx, m_host, ld, dm.as<double>(), num, num, c0, 9 - c0))) return rc;
+        if ((rc = ob_.fetch(ctx, num, status, nsteps, nreflect))) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return RAY_OK;
+    }
+    InitTables *tab = nullptr;
+    if ((rc = init_tables(ctx, prm, &tab))) return rc;
+    HostRing &ring = ctx->ring;
+    auto bail = [&](int code) {                            // nothing of this call stays in flight behind an error return
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ring.copy_stream);
+        return code;
+    };
+    for (int k = 0; k < nblk; ++k) {                       // every block's kernel, back to back
+        const int i0 = k * bsrc, cnt = std::min(bsrc, nsrc - i0);
+        if ((rc = shoot_block(ctx, med, ob, prm, tab, dm.as<double>(), num, i0, cnt, ob_.st.as<int32_t>(), ob_.ns.as<int32_t>(), ob_.nr.as<int32_t>())))
+            return bail(rc);
+        if (hipEventRecord(ring.blk_done[(size_t)k], ctx->stream) != hipSuccess) return bail(fail(RAY_ERR_HIP, "ray_shoot_to_exit: hipEventRecord failed"));
+    }
+    for (int k = 0; k <= nblk; ++k) {
+        if (k < nblk) {                                    // DMA of block k into slot k % 2 (block k - 2 has left it: delivered below, one turn ago)
+            const int i0 = k * bsrc, cnt = std::min(bsrc, nsrc - i0);
+            hipError_t e = hipStreamWaitEvent(ring.copy_stream, ring.blk_done[(size_t)k], 0);
+            if (e == hipSuccess) e = ring_enqueue_block(ctx, io, k % HostRing::kSlots, (int64_t)i0 * prm->nd, (int64_t)cnt * prm->nd);
+            if (e != hipSuccess) return bail(fail(RAY_ERR_HIP, std::string("ray_shoot_to_exit (ring): ") + hipGetErrorString(e)));
+        }
+        if (k >= 1) {                                      // block k - 1: wait for its DMA, copy it out while block k's DMA runs
+            const int j = k - 1, i0 = j * bsrc, cnt = std::min(bsrc, nsrc - i0);
+            if (hipEventSynchronize(ring.filled[j % HostRing::kSlots]) != hipSuccess) return bail(fail(RAY_ERR_HIP, "ray_shoot_to_exit (ring): hipEventSynchronize failed"));
+            ring_deliver_block(ctx, io, j % HostRing::kSlots, (int64_t)i0 * prm->nd, (int64_t)cnt * prm->nd);
+        }
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RAY_OK;
 }

@@ -394,3 +394,45 @@ def test_host_pointer_options_and_registered_arrays(ctx, orc):
     assert lib.ray_ctx_set_option(ctx.handle, 99, 1) == -1 and lib.ray_host_register(None, 8) == -1
     ctx.release_workspaces()                                 # staging released; the next call allocates again
     assert np.array_equal(ray_amd.ScatterRelation(sp, None, ns, nd, 1e-2, ctx=ctx), want)
+
+
+def test_host_pointer_pipeline_equals_device_path(ctx, orc):
+    """A sweep large enough to go out in blocks through the page-locked ring (ray_shoot_to_exit: block k's DMA beside
+    block k+1's kernel and the host threads' copy of block k-1): every row, status, step and reflection count equal to the
+    device-pointer entry point's single launch, with a ragged last block, a leading dimension larger than the row count,
+    some of the int outputs not asked for, and the skip-initial-columns option; twice in a row (slots are reused)."""
+    import hiprt
+    import ray_amd
+    from ray_amd import _lib
+    lib = _lib.load()
+    ns, nd, dt, N = 1100, 512, 1e-2, 129
+    c = orc.sinprod_grid(orc.OBSTACLE_DEMO, N, 1.5)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    ob = ray_amd.Circle(0.3)._struct()
+    prm = _lib.ShootParams(ns, nd, 0, ns, 0.0, math.pi, dt, 1, 0)
+    num, ld = ns * nd, ns * nd + 37
+    dm = hiprt.DevBuf(9 * num * 8)
+    dint = [hiprt.DevBuf(num * 4) for _ in range(3)]
+    assert lib.ray_shoot_to_exit_dev(ctx.handle, med.handle, C.byref(ob), C.byref(prm), dm.ptr, num, dint[0].ptr, dint[1].ptr, dint[2].ptr) == 0
+    ctx.synchronize()
+    want = dm.to_numpy(np.float64, 9 * num).reshape(9, num).T
+    wst, wns, wnr = (b.to_numpy(np.int32, num) for b in dint)
+    assert wnr.sum() > 1000
+    for rep in range(2):
+        m = np.full((ld, 9), -7.0, order="F")
+        st, nr = np.full(num, -1, dtype=np.int32), np.full(num, -1, dtype=np.int32)
+        assert lib.ray_shoot_to_exit(ctx.handle, med.handle, C.byref(ob), C.byref(prm), m.ctypes.data, ld, st.ctypes.data, None, nr.ctypes.data) == 0
+        assert np.array_equal(m[:num], want) and np.all(m[num:] == -7.0)
+        assert np.array_equal(st, wst) and np.array_equal(nr, wnr)
+    ctx.set_option(_lib.OPT_SKIP_INIT_COLUMNS, 1)
+    try:
+        m = np.full((ld, 9), -7.0, order="F")
+        ns_ = np.full(num, -1, dtype=np.int32)
+        assert lib.ray_shoot_to_exit(ctx.handle, med.handle, C.byref(ob), C.byref(prm), m.ctypes.data, ld, None, ns_.ctypes.data, None) == 0
+        assert np.all(m[:, 0:4] == -7.0) and np.array_equal(m[:num, 4:], want[:, 4:]) and np.array_equal(ns_, wns)
+    finally:
+        ctx.set_option(_lib.OPT_SKIP_INIT_COLUMNS, 0)
+    ctx.release_workspaces()                                 # the ring goes too; the next call builds it again
+    m = np.zeros((num, 9), order="F")
+    assert lib.ray_shoot_to_exit(ctx.handle, med.handle, C.byref(ob), C.byref(prm), m.ctypes.data, num, None, None, None) == 0
+    assert np.array_equal(m, want)
