@@ -170,8 +170,11 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 //  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
 //    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
 //    parked in the output row meanwhile.
+#ifndef RAY_SHOOT_WAVES
+#define RAY_SHOOT_WAVES 5
+#endif
 template <int MED, int OB, int AR, int PATH = 0>
-__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? 5 : 1) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? RAY_SHOOT_WAVES : 1) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
@@ -805,7 +808,7 @@ struct ray_ctx {
     int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
-    static constexpr int kPool = 7;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows)
+    static constexpr int kPool = 9;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows) | band offsets, M x (scatter passes)
     void *csr_pool[kPool] = {};
     size_t csr_cap[kPool] = {};
     // handles created on this context and not yet destroyed: ray_ctx_destroy releases their device memory
@@ -1850,7 +1853,7 @@ int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, i
 }
 
 // ---- complete forward operator: X, rho, Frechet matrix as device block rows (NEXT-1) -------------------
-enum { kFmIndptr = 0, kFmIndices, kFmData, kFmUoff, kFmUcols, kFmUvals, kFmRowcnt, kFmArrays };
+enum { kFmIndptr = 0, kFmIndices, kFmData, kFmUoff, kFmUcols, kFmUvals, kFmRowcnt, kFmBoff, kFmY, kFmArrays };
 static_assert(kFmArrays == ray_ctx::kPool, "pool slots");
 struct ray_frechet {
     ray_ctx *ctx = nullptr;
@@ -1862,6 +1865,10 @@ struct ray_frechet {
     void *arr[kFmArrays] = {};
     size_t cap[kFmArrays] = {};         // bytes behind them
     bool csr_built = false;
+    bool bands_built = false;           // kFmBoff: per ray and band of kBandNodes columns, where the band's entries start (k_br_band_offsets)
+    int nbands() const { return (int)(((int64_t)N * N + kBandNodes - 1) / kBandNodes); }
+    int32_t *boff() { return static_cast<int32_t *>(arr[kFmBoff]); }
+    double *ywork() { return static_cast<double *>(arr[kFmY]); }
     int64_t *indptr() { return static_cast<int64_t *>(arr[kFmIndptr]); }
     int32_t *indices() { return static_cast<int32_t *>(arr[kFmIndices]); }
     double *data() { return static_cast<double *>(arr[kFmData]); }
@@ -2269,16 +2276,44 @@ int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev)
     return RAY_OK;
 }
 
+// the band offsets of the scatter passes (ray_frechet.h): built on the first pass that needs them, kept with the matrix
+static int ensure_bands(ray_frechet *f)
+{
+    if (f->bands_built || f->num == 0) return RAY_OK;
+    const int nb = f->nbands();
+    HIPCHK(frechet_alloc(f, kFmBoff, sizeof(int32_t) * (size_t)(nb + 1) * (size_t)f->num));
+    HIPCHK(frechet_alloc(f, kFmY, sizeof(double) * 4 * (size_t)f->num));
+    hipLaunchKernelGGL(k_br_band_offsets, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), nb, f->boff());
+    HIPCHK(hipGetLastError());
+    f->bands_built = true;
+    return RAY_OK;
+}
+
+static int band_scatter(int mode, ray_frechet *f, const double *coef, const uint8_t *ray_mask_dev, double *out_dev)
+{
+    const size_t nn = (size_t)f->N * f->N;
+    HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double) * nn, f->ctx->stream));
+    if (f->num == 0) return RAY_OK;
+    int rc = ensure_bands(f);
+    if (rc) return rc;
+    const size_t lds = sizeof(double) * kBandNodes;   // 64 KB of dynamic LDS: above the default limit of a launch
+    const void *fn = mode == 0 ? reinterpret_cast<const void *>(&k_br_band_scatter<0>) : reinterpret_cast<const void *>(&k_br_band_scatter<1>);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((f->num + kBandRays - 1) / kBandRays), (unsigned)f->nbands());
+    if (mode == 0)
+        hipLaunchKernelGGL(k_br_band_scatter<0>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->rows(), f->boff(), coef, ray_mask_dev, (int64_t)nn, out_dev);
+    else
+        hipLaunchKernelGGL(k_br_band_scatter<1>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->rows(), f->boff(), coef, ray_mask_dev, (int64_t)nn, out_dev);
+    HIPCHK(hipGetLastError());
+    return RAY_OK;
+}
+
 int ray_frechet_matvec_t_dev(ray_frechet *f, const double *v_dev, const uint8_t *ray_mask_dev, double *b_dev)
 {
     int rc = check_frechet(f);
     if (rc) return rc;
     if (!v_dev || !b_dev) return fail(RAY_ERR_INVALID, "null argument");
-    HIPCHK(hipMemsetAsync(b_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
-    if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_br_matvec_t, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), v_dev, ray_mask_dev, b_dev);
-    HIPCHK(hipGetLastError());
-    return RAY_OK;
+    return band_scatter(0, f, v_dev, ray_mask_dev, b_dev);
 }
 
 int ray_frechet_normal_matvec_dev(ray_frechet *f, const double *x_dev, const uint8_t *ray_mask_dev, double *w_dev)
@@ -2286,11 +2321,12 @@ int ray_frechet_normal_matvec_dev(ray_frechet *f, const double *x_dev, const uin
     int rc = check_frechet(f);
     if (rc) return rc;
     if (!x_dev || !w_dev || x_dev == w_dev) return fail(RAY_ERR_INVALID, "null argument / x and w must differ");
-    HIPCHK(hipMemsetAsync(w_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
-    if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_br_normal_matvec, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), x_dev, ray_mask_dev, w_dev);
-    HIPCHK(hipGetLastError());
-    return RAY_OK;
+    if (f->num) {
+        if ((rc = ensure_bands(f))) return rc;
+        hipLaunchKernelGGL(k_br_matvec, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), x_dev, f->ywork());
+        HIPCHK(hipGetLastError());
+    }
+    return band_scatter(0, f, f->ywork(), ray_mask_dev, w_dev);
 }
 
 int ray_frechet_normal_diag_dev(ray_frechet *f, const uint8_t *ray_mask_dev, double *d_dev)
@@ -2298,11 +2334,7 @@ int ray_frechet_normal_diag_dev(ray_frechet *f, const uint8_t *ray_mask_dev, dou
     int rc = check_frechet(f);
     if (rc) return rc;
     if (!d_dev) return fail(RAY_ERR_INVALID, "null argument");
-    HIPCHK(hipMemsetAsync(d_dev, 0, sizeof(double) * (size_t)f->N * f->N, f->ctx->stream));
-    if (f->num == 0) return RAY_OK;
-    hipLaunchKernelGGL(k_br_normal_diag, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), ray_mask_dev, d_dev);
-    HIPCHK(hipGetLastError());
-    return RAY_OK;
+    return band_scatter(1, f, nullptr, ray_mask_dev, d_dev);
 }
 
 int ray_frechet_fidelity_update_dev(ray_frechet *f, const double *x_dev, const double *mismatch_dev,

@@ -73,8 +73,12 @@ constexpr int kSlotPieces = RAY_SLOT_PIECES;
 constexpr unsigned kSlotBytes = 16u * kSlotPieces;
 constexpr int kPasses = kSlotPieces;                // global_load_lds passes that fill them (P x 1 KiB = 64 slots x 16 P bytes)
 constexpr int kWaveSlotBytes = kPasses * 1024;
-constexpr int kTagEntries = 128;                    // per wave, 4 bytes each: (cell id << 6) | slot, or kTagEmpty
+#ifndef RAY_TAG_ENTRIES
+#define RAY_TAG_ENTRIES 128
+#endif
+constexpr int kTagEntries = RAY_TAG_ENTRIES;        // per wave, 4 bytes each: (cell id << 6) | slot, or kTagEmpty
 constexpr unsigned kTagEmpty = 0xffffffffu;
+static_assert(kTagEntries == 128 || kTagEntries == 64, "tags are cleared by one store per lane");
 constexpr int kWaveLdsBytes = kWaveSlotBytes + 64 * 4 + kTagEntries * 4;
 
 struct GridAcc {
@@ -161,7 +165,8 @@ __device__ __forceinline__ GridAcc grid_acc_setup(const GridDev &g)
     static_assert(kSlotPieces == 6 || kSlotPieces == 7, "slot pieces");
     // the cell-id slots are read speculatively by the loader lanes: keep them valid cell ids
     lds_st_u32(a.wcells + a.lane * 4u, 0u);
-    lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
+    if (kTagEntries == 128) lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
+    else lds_st_u32(a.wtags + a.lane * 4u, kTagEmpty);
     __syncthreads();
     return a;
 }
@@ -268,7 +273,8 @@ __device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a,
     }
 #endif
     // the slots are about to be overwritten: forget what the tags said about them
-    lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
+    if (kTagEntries == 128) lds_st_u2(a.wtags + a.lane * 8u, kTagEmpty, kTagEmpty);
+    else lds_st_u32(a.wtags + a.lane * 4u, kTagEmpty);
     if (leader) {
         lds_st_u32(a.wcells + rank * 4u, (unsigned)cid);
         lds_st_u32(tag_addr(a, i, j), ((unsigned)cid << 6) | rank);

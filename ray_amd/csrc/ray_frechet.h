@@ -1024,55 +1024,98 @@ __global__ __launch_bounds__(256) void k_br_matvec(const BlockRows m, const doub
     }
 }
 
-// b += M' (mask .* v): the rows of the selected rays scattered into b (NonObstacle.jl:354); one fp64 atomic
-// per distinct node (the four rows' contributions are added up first)
-__global__ __launch_bounds__(256) void k_br_matvec_t(const BlockRows m, const double *__restrict__ vec,
-                                                     const uint8_t *__restrict__ ray_mask, double *__restrict__ b)
+// ---- the passes that end in a sum over rays: b = M' v, w = M' (M x), d = diag(M' M) --------------------------------
+// The node range is cut into BANDS of kBandNodes consecutive columns (64 KB of fp64: one LDS tile); a ray's columns are
+// sorted, so its entries of one band are one contiguous piece of its block row -- found once per matrix by binary
+// search (k_br_band_offsets: `boff`, band-major) -- and a workgroup (band, chunk of rays) adds the pieces of its rays
+// into the tile with LDS atomics, then adds the tile's non-zero words to the result: 256 consecutive doubles per
+// instruction, and only (ray chunks) x N^2 of them instead of one global atomic per entry.  Sums are order-free (1e-12).
+#ifndef RAY_BAND_ABLATE
+#define RAY_BAND_ABLATE 0
+#endif
+constexpr int kBandNodes = 8192;
+constexpr int kBandThreads = 1024;               // 16 waves share a tile: two workgroups = 32 waves per CU
+constexpr int kBandRays = 4096;                  // rays per chunk (64 groups of 64: four per wave)
+
+// boff[b * num + ray] = first entry of `ray` (relative to uoff[ray]) whose column is >= b * kBandNodes, b = 0 .. nb
+__global__ __launch_bounds__(256) void k_br_band_offsets(const BlockRows m, int nb, int32_t *__restrict__ boff)
 {
     const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= m.num) return;
-    if (ray_mask && !ray_mask[ray]) return;
     const int lane = threadIdx.x & 63;
-    const double2 *v2 = reinterpret_cast<const double2 *>(vec + ray * 4);
-    const double2 lo = v2[0], hi = v2[1];
-    for (int64_t u = m.uoff[ray] + lane; u < m.uoff[ray + 1]; u += 64) {
-        double v[4];
-        m.load(u, v);
-        unsafeAtomicAdd(&b[m.ucols[u]], ((v[0] * lo.x + v[1] * lo.y) + v[2] * hi.x) + v[3] * hi.y);
+    const int64_t u0 = m.uoff[ray], n = m.uoff[ray + 1] - u0;
+    for (int b = lane; b <= nb; b += 64) {
+        const int64_t key = (int64_t)b * kBandNodes;
+        int64_t lo = 0, hi = n;                                   // first position with column >= key
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)m.ucols[u0 + mid] < key) lo = mid + 1; else hi = mid;
+        }
+        boff[(int64_t)b * m.num + ray] = (int32_t)lo;
     }
 }
 
-// The normal operator of the selected rays without forming it (the reference forms MtM = M[order,Idx]' * M[order,Idx],
-// NonObstacle.jl:353; at N = 1024 that product is out of reach, a Krylov solve needs only its action):
-//   w += M[order,:]' (M[order,:] x): the ray's four dots with x, then one atomic per node (the block row comes back from L2)
-__global__ __launch_bounds__(256) void k_br_normal_matvec(const BlockRows m, const double *__restrict__ x,
-                                                          const uint8_t *__restrict__ ray_mask, double *__restrict__ w)
+// MODE 0: out += M[rays,:]' * coef[rays] (coef: 4 per ray -- v for the gradient, M x for the normal operator)
+// MODE 1: out += sum of the squares of the rays' entries (diag(M' M))
+template <int MODE>
+__global__ __launch_bounds__(kBandThreads) void k_br_band_scatter(const BlockRows m, const int32_t *__restrict__ boff,
+                                                                  const double *__restrict__ coef, const uint8_t *__restrict__ ray_mask,
+                                                                  int64_t nn, double *__restrict__ out)
 {
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= m.num) return;
-    if (ray_mask && !ray_mask[ray]) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t b = m.uoff[ray], e = m.uoff[ray + 1];
-    double s[4];
-    br_dots(m, b, e, lane, x, s);
-    for (int64_t u = b + lane; u < e; u += 64) {
-        double v[4];
-        m.load(u, v);
-        unsafeAtomicAdd(&w[m.ucols[u]], ((v[0] * s[0] + v[1] * s[1]) + v[2] * s[2]) + v[3] * s[3]);
+    double *acc = reinterpret_cast<double *>(ray_smem);
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t col0 = (int64_t)b * kBandNodes;
+    for (int k = tid; k < kBandNodes; k += kBandThreads) acc[k] = 0.0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * kBandRays, r1 = r0 + kBandRays < m.num ? r0 + kBandRays : m.num;
+    const int32_t *lo_b = boff + (int64_t)b * m.num, *hi_b = lo_b + m.num;
+    for (int64_t g0 = r0 + (int64_t)wave * 64; g0 < r1; g0 += (kBandThreads / 64) * 64) {
+        // lane <-> ray: which of these 64 rays have entries in the band
+        const int64_t rr = g0 + lane;
+        int s = 0, e = 0;
+        if (rr < r1 && (!ray_mask || ray_mask[rr])) { s = lo_b[rr]; e = hi_b[rr]; }
+        unsigned long long todo = __ballot(e > s);
+        const int half = lane >> 5, l = lane & 31;
+        while (todo) {                                           // two rays at a time, 32 lanes each
+            const int i0 = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            int i1 = -1;
+            if (todo) { i1 = __builtin_ctzll(todo); todo &= todo - 1; }
+            const int pick = half ? i1 : i0;
+            const int src = pick < 0 ? 0 : pick;                  // every lane takes part in the shuffles
+            int sb = __shfl(s, src, 64), eb = __shfl(e, src, 64);
+            if (pick < 0) sb = eb = 0;                            // the upper half idles on an odd count
+            const int64_t ray = g0 + src;
+            const int64_t u0 = m.uoff[ray];
+            double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (MODE == 0) {
+                const double2 *cp = reinterpret_cast<const double2 *>(coef + ray * 4);
+                const double2 lo2 = cp[0], hi2 = cp[1];
+                c0 = lo2.x; c1 = lo2.y; c2 = hi2.x; c3 = hi2.y;
+            }
+            for (int64_t u = u0 + sb + l; u < u0 + eb; u += 32) {
+                double v[4];
+#if RAY_BAND_ABLATE == 2
+                v[0] = v[1] = v[2] = v[3] = 1.0;
+                const int col = (int)(col0 + ((u * 37) & (kBandNodes - 1)));
+#else
+                m.load(u, v);
+                const int col = m.ucols[u];
+#endif
+                const double t = MODE == 0 ? ((v[0] * c0 + v[1] * c1) + v[2] * c2) + v[3] * c3
+                                           : ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
+#if RAY_BAND_ABLATE == 1
+                acc[col - col0] = t;
+#else
+                atomicAdd(&acc[col - col0], t);                   // LDS: ds_add_f64
+#endif
+            }
+        }
     }
-}
-
-//   d[j] += sum over the selected rows of M[k,j]^2 = diag(MtM): the Jacobi preconditioner of that solve
-__global__ __launch_bounds__(256) void k_br_normal_diag(const BlockRows m, const uint8_t *__restrict__ ray_mask, double *__restrict__ d)
-{
-    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= m.num) return;
-    if (ray_mask && !ray_mask[ray]) return;
-    const int lane = threadIdx.x & 63;
-    for (int64_t u = m.uoff[ray] + lane; u < m.uoff[ray + 1]; u += 64) {
-        double v[4];
-        m.load(u, v);
-        unsafeAtomicAdd(&d[m.ucols[u]], ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]);
+    __syncthreads();
+    for (int k = tid; k < kBandNodes; k += kBandThreads) {
+        const double t = acc[k];
+        if (t != 0.0 && col0 + k < nn) unsafeAtomicAdd(&out[col0 + k], t);
     }
 }
 
