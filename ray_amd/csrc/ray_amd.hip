@@ -808,7 +808,7 @@ struct ray_ctx {
     int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
-    static constexpr int kPool = 9;            // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows) | band offsets, M x (scatter passes)
+    static constexpr int kPool = 11;           // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows) | band offsets, M x (scatter passes)
     void *csr_pool[kPool] = {};
     size_t csr_cap[kPool] = {};
     // handles created on this context and not yet destroyed: ray_ctx_destroy releases their device memory
@@ -1853,7 +1853,7 @@ int ray_trace_paths(ray_ctx *ctx, const ray_medium *med, const double *m_host, i
 }
 
 // ---- complete forward operator: X, rho, Frechet matrix as device block rows (NEXT-1) -------------------
-enum { kFmIndptr = 0, kFmIndices, kFmData, kFmUoff, kFmUcols, kFmUvals, kFmRowcnt, kFmBoff, kFmY, kFmArrays };
+enum { kFmIndptr = 0, kFmIndices, kFmData, kFmUoff, kFmUcols, kFmUvals, kFmRowcnt, kFmBstart, kFmBcols, kFmBvals, kFmY, kFmArrays };
 static_assert(kFmArrays == ray_ctx::kPool, "pool slots");
 struct ray_frechet {
     ray_ctx *ctx = nullptr;
@@ -1865,10 +1865,11 @@ struct ray_frechet {
     void *arr[kFmArrays] = {};
     size_t cap[kFmArrays] = {};         // bytes behind them
     bool csr_built = false;
-    bool bands_built = false;           // kFmBoff: per ray and band of kBandNodes columns, where the band's entries start (k_br_band_offsets)
+    bool bands_built = false;           // the band-major copy the scatter passes stream through (ray_frechet.h), made on first use
     int nbands() const { return (int)(((int64_t)N * N + kBandNodes - 1) / kBandNodes); }
-    int32_t *boff() { return static_cast<int32_t *>(arr[kFmBoff]); }
+    int64_t *bstart() { return static_cast<int64_t *>(arr[kFmBstart]); }
     double *ywork() { return static_cast<double *>(arr[kFmY]); }
+    BlockRows band_rows() { return BlockRows{nullptr, static_cast<const int32_t *>(arr[kFmBcols]), static_cast<const double *>(arr[kFmBvals]), num, droptol}; }
     int64_t *indptr() { return static_cast<int64_t *>(arr[kFmIndptr]); }
     int32_t *indices() { return static_cast<int32_t *>(arr[kFmIndices]); }
     double *data() { return static_cast<double *>(arr[kFmData]); }
@@ -2276,15 +2277,31 @@ int ray_frechet_matvec_dev(ray_frechet *f, const double *x_dev, double *y_dev)
     return RAY_OK;
 }
 
-// the band offsets of the scatter passes (ray_frechet.h): built on the first pass that needs them, kept with the matrix
+// the band-major copy of the scatter passes (ray_frechet.h): built on the first pass that needs it, kept with the matrix
 static int ensure_bands(ray_frechet *f)
 {
     if (f->bands_built || f->num == 0) return RAY_OK;
+    ray_ctx *ctx = f->ctx;
     const int nb = f->nbands();
-    HIPCHK(frechet_alloc(f, kFmBoff, sizeof(int32_t) * (size_t)(nb + 1) * (size_t)f->num));
+    const int64_t cells = (int64_t)nb * f->num;
+    DevBuf boff, blen;
+    HIPCHK(boff.alloc(sizeof(int32_t) * (size_t)(cells + f->num)));
+    HIPCHK(blen.alloc(sizeof(int32_t) * (size_t)cells));
+    HIPCHK(frechet_alloc(f, kFmBstart, sizeof(int64_t) * (size_t)(cells + 1)));
+    HIPCHK(frechet_alloc(f, kFmBcols, sizeof(int32_t) * (size_t)(f->U ? f->U : 1)));
+    HIPCHK(frechet_alloc(f, kFmBvals, sizeof(double) * 4 * (size_t)(f->U ? f->U : 1)));
     HIPCHK(frechet_alloc(f, kFmY, sizeof(double) * 4 * (size_t)f->num));
-    hipLaunchKernelGGL(k_br_band_offsets, dim3(wave_rows_grid(f->num)), dim3(256), 0, f->ctx->stream, f->rows(), nb, f->boff());
+    hipLaunchKernelGGL(k_br_band_offsets, dim3(wave_rows_grid(f->num)), dim3(256), 0, ctx->stream, f->rows(), nb, boff.as<int32_t>());
+    hipLaunchKernelGGL(k_br_band_lengths, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, boff.as<int32_t>(), cells, f->num, blen.as<int32_t>());
     HIPCHK(hipGetLastError());
+    int64_t total = 0;
+    int rc = scan_counts(ctx, blen.as<int32_t>(), cells, f->bstart(), &total);
+    if (rc) return rc;
+    if (total != f->U) return fail(RAY_ERR_HIP, "band copy: the pieces do not add up to the block rows (columns of a ray not sorted?)");
+    hipLaunchKernelGGL(k_br_band_copy, dim3(wave_rows_grid(f->num)), dim3(256), 0, ctx->stream, f->rows(), boff.as<int32_t>(), f->bstart(), nb,
+                       static_cast<int32_t *>(f->arr[kFmBcols]), static_cast<double *>(f->arr[kFmBvals]));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));          // boff / blen are released on return
     f->bands_built = true;
     return RAY_OK;
 }
@@ -2301,9 +2318,9 @@ static int band_scatter(int mode, ray_frechet *f, const double *coef, const uint
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)((f->num + kBandRays - 1) / kBandRays), (unsigned)f->nbands());
     if (mode == 0)
-        hipLaunchKernelGGL(k_br_band_scatter<0>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->rows(), f->boff(), coef, ray_mask_dev, (int64_t)nn, out_dev);
+        hipLaunchKernelGGL(k_br_band_scatter<0>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->band_rows(), f->bstart(), coef, ray_mask_dev, (int64_t)nn, out_dev);
     else
-        hipLaunchKernelGGL(k_br_band_scatter<1>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->rows(), f->boff(), coef, ray_mask_dev, (int64_t)nn, out_dev);
+        hipLaunchKernelGGL(k_br_band_scatter<1>, grid, dim3(kBandThreads), lds, f->ctx->stream, f->band_rows(), f->bstart(), coef, ray_mask_dev, (int64_t)nn, out_dev);
     HIPCHK(hipGetLastError());
     return RAY_OK;
 }
