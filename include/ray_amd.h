@@ -119,6 +119,21 @@ int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
  *                              starting point each -- so the reference's own call NonReflectionTrace(c, m, ext, dt)
  *                              (Obstacle.jl:275) needs no hint; the _dev entry points take m as it is told.         */
 #define RAY_OPT_FAN_DIRECTIONS 3
+/*   RAY_OPT_TUNE_*             kernel shapes for experiments and tests; results never depend on them.  They are options of
+ *                              the context on purpose: the library reads NO environment variable, so nothing outside the
+ *                              caller's own calls changes what its process launches.
+ *                                BLOCK_THREADS 64 | 128 | 256 (default)   workgroup size of the integration kernels
+ *                                WAVE_DIRS 0 (automatic) | 4 .. 64        directions per wavefront of the fan mapping
+ *                                SORT_KEY_BITS 0 (automatic) | 64         key width of the Frechet merge's sort
+ *                                FRECHET_LDS_ROWS -1 (default) | n        longest ray whose records the merge keeps in LDS
+ *                                MERGE_GRID 0 (one per ray) | n           workgroups of the merge's emit kernel
+ *                                FRECHET_SLAB_MB 0 (a quarter of free memory) | n   trajectory slab budget per chunk of rays */
+#define RAY_OPT_TUNE_BLOCK_THREADS    4
+#define RAY_OPT_TUNE_WAVE_DIRS        5
+#define RAY_OPT_TUNE_SORT_KEY_BITS    6
+#define RAY_OPT_TUNE_FRECHET_LDS_ROWS 7
+#define RAY_OPT_TUNE_MERGE_GRID       8
+#define RAY_OPT_TUNE_FRECHET_SLAB_MB  9
 int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
 /* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by
  * ray_ctx_release_workspaces / ray_ctx_destroy) and copy to / from the caller's arrays.  From pageable memory

@@ -98,7 +98,7 @@ function context(device::Integer = 0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:ray_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
         CTX[] = h[]
-        atexit(() -> (ccall((:ray_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), CTX[]); CTX[] = C_NULL))
+        atexit(() -> (empty!(GRID_MEDIA); ccall((:ray_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), CTX[]); CTX[] = C_NULL))
     end
     CTX[]
 end
@@ -130,17 +130,27 @@ function with_medium(f, c::RadialSineSum)
     end
 end
 
+# Gridded media are kept per (N, ext): the reconstruction loop calls ScatterForwardOperator / the traces with a new c0 of
+# the same size every iteration (NonObstacle.jl:331-333), so the handle (tables, hess records, their device memory)
+# is created once and every later call re-uploads the nodal values with ray_medium_update_grid (one copy + one table
+# build on the device) instead of four allocations and their release.  Freed with the context (ray_ctx_destroy
+# releases every medium still alive on it).
+const GRID_MEDIA = Dict{Tuple{Int,Float64},Ptr{Cvoid}}()
 function with_medium(f, c::Matrix{Float64}, ext::Float64)
     N = size(c, 1)
     size(c, 2) == N || error("c must be N x N")
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:ray_medium_create_grid, LIB), Cint,
-                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), context(), c, N, ext, h))
-    try
-        f(h[])
-    finally
-        ccall((:ray_medium_destroy, LIB), Cint, (Ptr{Cvoid},), h[])
+    ctx = context()
+    h = get(GRID_MEDIA, (N, ext), C_NULL)
+    if h == C_NULL
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ray_medium_create_grid, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Ref{Ptr{Cvoid}}), ctx, c, N, ext, r))
+        h = r[]
+        GRID_MEDIA[(N, ext)] = h
+    else
+        check(ccall((:ray_medium_update_grid, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, c))
     end
+    f(h)
 end
 
 same_or_nothing(a, b, what) = (b === nothing || b === a || b == a) ||

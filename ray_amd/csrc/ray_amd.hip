@@ -806,6 +806,8 @@ struct ray_ctx {
     bool skip_init_cols = false;               // RAY_OPT_SKIP_INIT_COLUMNS
     int src_stride = 1;                        // RAY_OPT_SOURCE_STRIDE
     int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
+    // tuning / test options (RAY_OPT_TUNE_*): explicit per-context settings, never read from the environment
+    int tune_block = 256, tune_wave_dirs = 0, tune_sort_key = 0, tune_lds_rows = -1, tune_merge_grid = 0, tune_slab_mb = 0;
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
     static constexpr int kPool = 11;           // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows) | band offsets, M x (scatter passes)
@@ -1270,19 +1272,11 @@ static MediumDev medium_dev(const ray_medium *m)
     return d;
 }
 
-// workgroup size of the integration kernels (multiple of 64); RAY_BLOCK overrides for experiments
-static int block_threads()
-{
-    static int b = [] {
-        const char *e = getenv("RAY_BLOCK");
-        int v = e ? atoi(e) : 256;
-        return (v == 64 || v == 128 || v == 256) ? v : 256;
-    }();
-    return b;
-}
+// workgroup size of the integration kernels (multiple of 64); RAY_OPT_TUNE_BLOCK_THREADS overrides for experiments
+static int block_threads(const ray_ctx *ctx) { return ctx->tune_block; }
 static size_t nodes_lds_bytes(const ray_medium *med, bool fused)
 {
-    return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads(), !fused) : 0;   // no node table in kFused
+    return med->kind == kGrid ? grid_lds_bytes(med->N, block_threads(med->ctx), !fused) : 0;   // no node table in kFused
 }
 
 // Wave shape of the fan mapping: a patch of 2^(6-dshift) adjacent sources x 2^dshift directions.  Default 2 x 32
@@ -1346,19 +1340,16 @@ static int launch_shoot(ray_ctx *ctx, const ray_medium *med, const ray_obstacle 
     a.step_counter = ctx->d_steps;
     if (a.max_steps <= 0) a.max_steps = 1000000;
     if (a.num == 0) return RAY_OK;
-    const int bt = block_threads(), wpb = bt / 64;
+    const int bt = block_threads(ctx), wpb = bt / 64;
     unsigned nblk;
     if (a.init) {
         // wave shape: a patch of 2 adjacent sources x 32 directions by default (narrower fans touch fewer
         // distinct cells per wave than 64 directions of one source: +3..7 % on every gridded workload,
         // profiles/r1/ablations.md); fewer directions than that -> more sources per wave.
-        // RAY_WAVE_DIRS=64/32/16/8/4 overrides.
-        static const int env_dshift = [] {
-            const char *e = getenv("RAY_WAVE_DIRS");
-            const int v = e ? atoi(e) : 0;
-            return v == 64 ? 6 : v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 0;
-        }();
-        const int dshift = env_dshift ? env_dshift : pick_dshift(a.nd, a.nsrc, wpb);
+        // RAY_OPT_TUNE_WAVE_DIRS = 64/32/16/8/4 overrides.
+        const int v = ctx->tune_wave_dirs;
+        const int opt_dshift = v == 64 ? 6 : v == 32 ? 5 : v == 16 ? 4 : v == 8 ? 3 : v == 4 ? 2 : 0;
+        const int dshift = opt_dshift ? opt_dshift : pick_dshift(a.nd, a.nsrc, wpb);
         a.dshift = dshift;
         const int spb = wpb << (6 - dshift), dpw = 1 << dshift;      // sources per block, directions per wave
         a.ngroup = (a.nsrc + spb - 1) / spb;
@@ -1758,9 +1749,9 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     a.max_steps = 10000000;
     a.X = X_dev; a.ldx = ldx; a.status = status_dev; a.nsteps = nsteps_dev;
     a.step_counter = ctx->d_steps;
-    unsigned nblk = (unsigned)((num + block_threads() - 1) / block_threads());
+    unsigned nblk = (unsigned)((num + block_threads(ctx) - 1) / block_threads(ctx));
     if (fan > 0 && num % fan == 0) {                        // the rows are fans of `fan` directions: k_shoot's mapping
-        const int wpb = block_threads() / 64;
+        const int wpb = block_threads(ctx) / 64;
         a.nd = fan;
         a.nsrc = (int)(num / fan);
         const int dshift = pick_dshift(a.nd, a.nsrc, wpb);
@@ -1771,7 +1762,7 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     }
     hipEvent_t e0, e1;
     time_begin(ctx, e0, e1);
-    const dim3 tgrid(nblk), tblock(block_threads());
+    const dim3 tgrid(nblk), tblock(block_threads(ctx));
     if (path_dev) {
         a.path = path_dev; a.npts = npts_dev; a.max_pts = max_pts;
         if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL((k_trace<kFused, 1>), tgrid, tblock, nodes_lds_bytes(med, true), ctx->stream, a);
@@ -2034,11 +2025,10 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     int n2 = 256;
     while (n2 < frechet_entries(cap_max)) n2 <<= 1;
     // 32-bit sort keys when node index and emission index fit together (N <= 724 at the largest n2 = 4096
-    // that leaves room, N <= 1448 at n2 <= 1024, ...); RAY_SORT_KEY=64 forces the wide keys
+    // that leaves room, N <= 1448 at n2 <= 1024, ...); RAY_OPT_TUNE_SORT_KEY_BITS = 64 forces the wide keys
     int eshift = 0;
     while ((1 << eshift) < n2) ++eshift;
-    const char *env_key = getenv("RAY_SORT_KEY");                        // read per call: the tests switch it
-    const bool env_wide = env_key && atoi(env_key) == 64;
+    const bool env_wide = ctx->tune_sort_key == 64;                      // RAY_OPT_TUNE_SORT_KEY_BITS
     const bool narrow_key = !env_wide && eshift < 32 && (uint64_t)med->N * (uint64_t)med->N < (1ull << (32 - eshift)) - 1;
     const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8);
     if (narrow_key) {
@@ -2056,13 +2046,11 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, f->uoff(), &f->U))) return rc;
     HIPCHK(frechet_alloc(f, kFmUcols, sizeof(int32_t) * (size_t)(f->U ? f->U : 1)));
     HIPCHK(frechet_alloc(f, kFmUvals, sizeof(double) * 4 * (size_t)(f->U ? f->U : 1)));
-    // the ray's records sit in LDS during the merge when they fit (42 KiB = 224 rows of 144 + 48 B; RAY_FRECHET_LDS_ROWS for the tests)
-    const char *env_rows = getenv("RAY_FRECHET_LDS_ROWS");
+    // the ray's records sit in LDS during the merge when they fit (42 KiB = 224 rows of 144 + 48 B; RAY_OPT_TUNE_FRECHET_LDS_ROWS for the tests)
     int lds_rows = std::min(frechet_rows(cap_max), kMergeLdsMaxRows);
-    if (env_rows) lds_rows = std::max(0, std::min(lds_rows, atoi(env_rows)));
-    // one workgroup per ray; RAY_MERGE_GRID (tests, experiments) makes fewer workgroups loop over the rays instead
-    const char *env_grid = getenv("RAY_MERGE_GRID");
-    const int64_t emit_grid = env_grid ? std::max<int64_t>(1, std::min<int64_t>(num, atoi(env_grid))) : num;
+    if (ctx->tune_lds_rows >= 0) lds_rows = std::min(lds_rows, ctx->tune_lds_rows);
+    // one workgroup per ray; RAY_OPT_TUNE_MERGE_GRID (tests, experiments) makes fewer workgroups loop over the rays instead
+    const int64_t emit_grid = ctx->tune_merge_grid > 0 ? std::min<int64_t>(num, ctx->tune_merge_grid) : num;
     hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes, ctx->stream,
                        dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),
                        drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
@@ -2125,8 +2113,7 @@ int ray_forward_operator(ray_ctx *ctx, ray_medium *med, const double *m_host, in
     // waves) that keep them within a budget, and the block rows are concatenated (ray-ordered, chunks contiguous).
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { ray_frechet_destroy(f); return fail(RAY_ERR_HIP, "hipMemGetInfo failed"); }
-    const char *env_slab = getenv("RAY_FRECHET_SLAB_MB");                 // tests force small chunks with it
-    const double env_mb = env_slab ? atof(env_slab) : 0.0;
+    const double env_mb = (double)ctx->tune_slab_mb;                      // RAY_OPT_TUNE_FRECHET_SLAB_MB: tests force small chunks with it
     const double budget = env_mb > 0 ? env_mb * 1048576.0 : std::min((double)free_b / 4, 16.0 * 1073741824.0);
     std::vector<int64_t> cuts{0};
     {
@@ -2634,6 +2621,24 @@ int ray_ctx_set_option(ray_ctx *ctx, int option, int value)
         ctx->src_stride = value;
         return RAY_OK;
     }
+    if (option == RAY_OPT_TUNE_BLOCK_THREADS) {
+        if (value != 64 && value != 128 && value != 256) return fail(RAY_ERR_INVALID, "block threads: 64, 128 or 256");
+        ctx->tune_block = value;
+        return RAY_OK;
+    }
+    if (option == RAY_OPT_TUNE_WAVE_DIRS) {
+        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return fail(RAY_ERR_INVALID, "wave directions: 0 (automatic), 4, 8, 16, 32 or 64");
+        ctx->tune_wave_dirs = value;
+        return RAY_OK;
+    }
+    if (option == RAY_OPT_TUNE_SORT_KEY_BITS) {
+        if (value != 0 && value != 64) return fail(RAY_ERR_INVALID, "sort key bits: 0 (automatic) or 64");
+        ctx->tune_sort_key = value;
+        return RAY_OK;
+    }
+    if (option == RAY_OPT_TUNE_FRECHET_LDS_ROWS) { ctx->tune_lds_rows = value < 0 ? -1 : value; return RAY_OK; }
+    if (option == RAY_OPT_TUNE_MERGE_GRID) { ctx->tune_merge_grid = value < 0 ? 0 : value; return RAY_OK; }
+    if (option == RAY_OPT_TUNE_FRECHET_SLAB_MB) { ctx->tune_slab_mb = value < 0 ? 0 : value; return RAY_OK; }
     return fail(RAY_ERR_INVALID, "unknown option");
 }
 

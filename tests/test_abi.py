@@ -147,3 +147,11 @@ int main(void) {
     exe = tmp_path / "mk"
     subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
     assert subprocess.check_output([str(exe)], text=True).strip() == "0"
+
+
+def test_library_reads_no_environment_variable():
+    """kernel shapes are options of the context (RAY_OPT_TUNE_*), never environment variables that would change a
+    caller's launches behind its back (robustness 14)."""
+    for f in os.listdir(os.path.join(ROOT, "ray_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "ray_amd", "csrc", f)).read(), f

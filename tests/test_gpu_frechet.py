@@ -196,14 +196,31 @@ def test_reconstruction_loop_passes(ctx, orc):
     F.close()
 
 
-def test_forward_operator_chunked_equals_single(ctx, orc, monkeypatch):
+class tuned:
+    """RAY_OPT_TUNE_* options of the context for the length of a `with` block."""
+
+    def __init__(self, ctx, **kv):
+        from ray_amd import _lib
+        self.ctx, self.kv, self.lib = ctx, kv, _lib
+        self.defaults = {"FRECHET_SLAB_MB": 0, "FRECHET_LDS_ROWS": -1, "MERGE_GRID": 0, "SORT_KEY_BITS": 0}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.ctx.set_option(getattr(self.lib, "OPT_TUNE_" + k), v)
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            self.ctx.set_option(getattr(self.lib, "OPT_TUNE_" + k), self.defaults[k])
+
+
+def test_forward_operator_chunked_equals_single(ctx, orc):
     """a slab budget of 1 MB forces several ray chunks: the concatenated CSR is identical."""
     import ray_amd
     c, tab, m = _data(orc, 61, 12, 40, 1)                         # 480 rays, 8 waves
     med = ray_amd.GridMedium(c, 1.5, ctx)
     M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
-    monkeypatch.setenv("RAY_FRECHET_SLAB_MB", "1")
-    M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
+    with tuned(ctx, FRECHET_SLAB_MB=1):
+        M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
     assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
     assert np.array_equal(M1.data, M2.data)
     assert np.array_equal(s1, s2) and np.array_equal(i1["rho"], i2["rho"])
@@ -211,9 +228,9 @@ def test_forward_operator_chunked_equals_single(ctx, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("lds_rows", [0, 20])
-def test_forward_operator_merge_paths_agree(ctx, orc, monkeypatch, lds_rows):
+def test_forward_operator_merge_paths_agree(ctx, orc, lds_rows):
     """k_merge_emit keeps a ray's records and sorted entries in LDS when they fit and reads them in place
-    otherwise (rays of more than 224 steps): identical matrix either way (RAY_FRECHET_LDS_ROWS caps the LDS form;
+    otherwise (rays of more than 224 steps): identical matrix either way (RAY_OPT_TUNE_FRECHET_LDS_ROWS caps the LDS form;
     at 20 the rays of this case split between the two forms); block rows against the exported CSR."""
     import ray_amd
     import hiprt
@@ -221,10 +238,8 @@ def test_forward_operator_merge_paths_agree(ctx, orc, monkeypatch, lds_rows):
     med = ray_amd.GridMedium(c, 1.5, ctx)
     M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, 2e-2, ctx=ctx, info=True)
     assert i1["nsteps"].min() < 19 < i1["nsteps"].max()
-    monkeypatch.setenv("RAY_FRECHET_LDS_ROWS", str(lds_rows))
-    if lds_rows:
-        monkeypatch.setenv("RAY_MERGE_GRID", "7")                 # and seven workgroups looping over the 240 rays
-    F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 2e-2, ctx=ctx, droptol=1e-12)
+    with tuned(ctx, FRECHET_LDS_ROWS=lds_rows, MERGE_GRID=7 if lds_rows else 0):   # (7: seven workgroups looping over the 240 rays)
+        F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, 2e-2, ctx=ctx, droptol=1e-12)
     M2 = F.tocsr()
     assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
     assert np.array_equal(M1.data, M2.data)
@@ -248,15 +263,15 @@ def test_forward_operator_merge_paths_agree(ctx, orc, monkeypatch, lds_rows):
 
 
 @pytest.mark.parametrize("N,ns,nd,dt", [(61, 6, 40, 2e-2), (75, 3, 70, 2e-2)])
-def test_forward_operator_sort_key_widths_agree(ctx, orc, monkeypatch, N, ns, nd, dt):
+def test_forward_operator_sort_key_widths_agree(ctx, orc, N, ns, nd, dt):
     """k_merge_sort runs on 32-bit keys when node and emission index fit together and on 64-bit keys
-    otherwise: identical CSR either way (RAY_SORT_KEY=64 forces the wide keys)."""
+    otherwise: identical CSR either way (RAY_OPT_TUNE_SORT_KEY_BITS = 64 forces the wide keys)."""
     import ray_amd
     c, tab, m = _data(orc, N, ns, nd, 1, bump=0.3)
     med = ray_amd.GridMedium(c, 1.5, ctx)
     M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
-    monkeypatch.setenv("RAY_SORT_KEY", "64")
-    M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+    with tuned(ctx, SORT_KEY_BITS=64):
+        M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
     assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices)
     assert np.array_equal(M1.data, M2.data) and np.array_equal(s1, s2)
     Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
