@@ -16,13 +16,13 @@ cur = None
 for line in open(os.path.join(src, "pmc_summary.txt")):
     if not line.startswith(" "):
         cur = line.strip()
-    elif cur and "k_shoot" in cur:
+    elif cur and "k_shoot<1, 0, 1, 0>" in cur:
         name, _, rest = line.strip().partition(" ")
         vals[name] = float(rest.split("mean/dispatch")[1].split()[0])
 avg_ms = None
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_shoot" in row["Name"]:
+        if "k_shoot<1, 0, 1, 0>" in row["Name"]:
             avg_ms = float(row["AverageNs"]) * 1e-6
             calls, mn, mx = int(row["Calls"]), float(row["MinNs"]) * 1e-6, float(row["MaxNs"]) * 1e-6
 fetch = vals["FETCH_SIZE"] * 1024 * 2

@@ -7,5 +7,5 @@ OUT=$PWD/gpurun_out/prof_$TAG/pmc_$GROUP
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "pmc $GROUP rc=$?"
