@@ -155,7 +155,9 @@ def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num
     e1.record()
     e1.synchronize()
     nm_ms = e0.elapsed_time(e1) / reps
-    out["normal_matvec"] = {"workload": "w = M'(M x) on the block rows of that matrix (k_br_normal_matvec)", "kernel_ms": nm_ms,
+    out["normal_matvec"] = {"workload": "w = M'(M x) on the block rows of that matrix: y = M x (k_br_matvec, ray-major rows) then "
+                                        "w = M'y (k_br_band_scatter, band-major copy); 36 B per entry and pass (4 f64 + one index word)",
+                            "kernel_ms": nm_ms,
                             "block_row_entries": int(n_entries), "algorithmic_bytes": int(n_entries) * 36 * 2,
                             "hbm_frac": int(n_entries) * 36 * 2 / (nm_ms * 1e-3) / 8.0e12}
     F.close()

@@ -1460,14 +1460,22 @@ int ray_shoot_to_exit_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacl
 
 static int copy_cols_h2d(ray_ctx *ctx, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int c0, int ncol)
 {
-    HIPCHK(hipMemcpy2DAsync(dst + (size_t)c0 * ldd, (size_t)ldd * 8, src + (size_t)c0 * lds, (size_t)lds * 8,
-                            (size_t)rows * 8, (size_t)ncol, hipMemcpyHostToDevice, ctx->stream));
+    if (ldd == rows && lds == rows) {                  // the columns abut on both sides: one flat copy
+        HIPCHK(hipMemcpyAsync(dst + (size_t)c0 * ldd, src + (size_t)c0 * lds, (size_t)rows * 8 * (size_t)ncol, hipMemcpyHostToDevice, ctx->stream));
+        return RAY_OK;
+    }
+    for (int c = c0; c < c0 + ncol; ++c)               // one flat copy per column (at most nine)
+        HIPCHK(hipMemcpyAsync(dst + (size_t)c * ldd, src + (size_t)c * lds, (size_t)rows * 8, hipMemcpyHostToDevice, ctx->stream));
     return RAY_OK;
 }
 static int copy_cols_d2h(ray_ctx *ctx, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int c0, int ncol)
 {
-    HIPCHK(hipMemcpy2DAsync(dst + (size_t)c0 * ldd, (size_t)ldd * 8, src + (size_t)c0 * lds, (size_t)lds * 8,
-                            (size_t)rows * 8, (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+    if (ldd == rows && lds == rows) {                  // the columns abut on both sides: one flat copy
+        HIPCHK(hipMemcpyAsync(dst + (size_t)c0 * ldd, src + (size_t)c0 * lds, (size_t)rows * 8 * (size_t)ncol, hipMemcpyDeviceToHost, ctx->stream));
+        return RAY_OK;
+    }
+    for (int c = c0; c < c0 + ncol; ++c)               // one flat copy per column (at most nine)
+        HIPCHK(hipMemcpyAsync(dst + (size_t)c * ldd, src + (size_t)c * lds, (size_t)rows * 8, hipMemcpyDeviceToHost, ctx->stream));
     return RAY_OK;
 }
 

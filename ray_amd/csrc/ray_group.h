@@ -123,6 +123,9 @@ static hipError_t comb_copy(const GroupMember &m, void *host, void *dev, size_t 
     if (m.count == 0) return hipSuccess;
     char *h = static_cast<char *>(host) + (size_t)m.row0 * w;
     const size_t piece = (size_t)m.nd * w, hpitch = piece * (size_t)m.G;
+    if (m.G == 1)                                       // a group of one: the share is the whole array, one flat copy
+        return to_host ? hipMemcpyAsync(h, dev, piece * (size_t)m.count, hipMemcpyDeviceToHost, m.ctx->stream)
+                       : hipMemcpyAsync(dev, h, piece * (size_t)m.count, hipMemcpyHostToDevice, m.ctx->stream);
     return to_host ? hipMemcpy2DAsync(h, hpitch, dev, piece, piece, (size_t)m.count, hipMemcpyDeviceToHost, m.ctx->stream)
                    : hipMemcpy2DAsync(dev, piece, h, hpitch, piece, (size_t)m.count, hipMemcpyHostToDevice, m.ctx->stream);
 }
