@@ -6,6 +6,7 @@ unbroken rays with ScatterForwardOperator, the `perc` selection mask, M'v and th
 the GPU, and a dense host solve for A \\ b.  Plotting and timers dropped.
 
     python examples/obstacle_reconstruction.py [--ns 50 --nd 300 --N 45 --iters 50]
+    python examples/obstacle_reconstruction.py --stage-two      # ObstacleDemo.jl:42-71 only: draw the obstacle
 """
 import argparse
 import json
@@ -71,15 +72,38 @@ def reconstruct(ns, nd, N, iters, ctx, log=print):
     return c0, hist, cls
 
 
+def draw_obstacle(ns, nd, ctx, N=257):
+    """Stage two of ObstacleDemo.jl (:42-71): the rays that return to their source with reversed momentum hit the
+    obstacle at normal incidence half way through their time; traced that long without the obstacle, their end points
+    draw it.  Returns the end points (k, 2) and their level-set values."""
+    import ray_amd
+    sp, ob = ray_amd.SinProd.obstacle_demo(), ray_amd.Circle(0.3)
+    dt, ext = 5e-3, 1.5                                                              # accurateTimeStep, :42
+    m = ray_amd.ScatterRelationObstacle(sp, sp, ob, ob, ns, nd, dt, ctx=ctx)         # :43 (t counted in steps)
+    ortho = ray_amd.classify_rays(m, ns, nd, ctx=ctx)["ortho_index"]                 # :48-49
+    m[:, 8] *= dt / 2                                                                # :50: half the time, in seconds
+    p = np.zeros(N)
+    ray_amd._lib.check(ctx._lib.ray_linspace(-ext, ext, N, p.ctypes.data))
+    c = np.asfortranarray([[sp(float(x), float(y)) for y in p] for x in p])
+    ends = ray_amd.NonReflectionTrace(c, np.asfortranarray(m[ortho]), ext, dt, ctx=ctx)[:, 4:6]   # :51 (the plot's end points)
+    return ends, np.hypot(ends[:, 0], ends[:, 1]) - 0.3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ns", type=int, default=50)
     ap.add_argument("--nd", type=int, default=300)
     ap.add_argument("--N", type=int, default=45)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--stage-two", action="store_true", help="only draw the obstacle from the orthogonal hits")
     args = ap.parse_args()
     import ray_amd
     ctx = ray_amd.Context(0)
+    if args.stage_two:
+        ends, lev = draw_obstacle(args.ns, args.nd, ctx)
+        print(json.dumps({"orthogonal_hits": int(ends.shape[0]), "max_abs_level_set_at_end_points": float(np.abs(lev).max()),
+                          "median_abs_level_set": float(np.median(np.abs(lev)))}))
+        return
     c0, hist, cls = reconstruct(args.ns, args.nd, args.N, args.iters, ctx)
     print(json.dumps({"orthogonal_hits": int(cls["ortho_index"].size), "unbroken_rays": int(cls["unbroken"].size)}))
 

@@ -39,3 +39,17 @@ def test_obstacle_workflow_converges(ctx):
     assert cls["unbroken"].size > 0 and cls["unbroken"].size < 24 * 120        # the obstacle breaks some fans
     assert all(b < a for a, b in zip(obj, obj[1:])), obj
     assert obj[-1] < 0.6 * obj[0], obj
+
+
+def test_obstacle_example_stage_two_draws_the_circle(ctx):
+    """examples/obstacle_reconstruction.py --stage-two (ObstacleDemo.jl:42-71): the end points of the half-time traces of
+    the orthogonal hits lie on the circle r = 0.3 up to O(dt) and the filter's 5.7 degrees (the per-ray bound with the
+    oracle beside it is tests/test_gpu_parity.py::test_obstacle_demo_stage_two_draws_the_obstacle)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    spec = importlib.util.spec_from_file_location("recon_ob2", os.path.join(ROOT, "examples", "obstacle_reconstruction.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ends, lev = mod.draw_obstacle(50, 300, ctx)
+    assert ends.shape[0] >= 150
+    assert float(np.median(np.abs(lev))) < 0.02 and float(np.abs(lev).max()) < 0.04, (float(np.median(np.abs(lev))), float(np.abs(lev).max()))
