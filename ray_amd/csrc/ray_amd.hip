@@ -439,8 +439,11 @@ struct TraceArgs {
 // the clock is per lane here (every ray has its own T and its own shortened last step).
 // PATH = 1 also records `res` of NonReflectionPlot (Obstacle.jl:256,266): the start and the position after
 // every step.
+#ifndef RAY_TRACE_WAVES
+#define RAY_TRACE_WAVES 4               // waves per SIMD of the fused trace kernel (114 VGPRs; 5 = 96 VGPRs with 10 spilled was 2 % slower: profiles/r3)
+#endif
 template <int AR, int PATH = 0>
-__global__ __launch_bounds__(256) void k_trace(const TraceArgs a)
+__global__ __launch_bounds__(256, (AR == kFused && !PATH) ? RAY_TRACE_WAVES : 1) void k_trace(const TraceArgs a)
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool valid = r < a.num;

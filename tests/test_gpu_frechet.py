@@ -394,3 +394,40 @@ def test_forward_operator_n513_entry_for_entry(ctx, orc, arith):
     pat_d = sps.csr_matrix((np.ones(Md.nnz), Md.indices, Md.indptr), shape=Md.shape)
     pat_k = sps.csr_matrix((np.ones(keep.nnz), keep.indices, keep.indptr), shape=keep.shape)
     assert abs(pat_d - pat_k).sum() <= 1e-5 * keep.nnz              # entries within rounding of the threshold may differ
+
+
+def test_config5_grid_operator_and_normal_passes_vs_oracle(ctx, orc):
+    """BASELINE config 5's grid (N = 1024, dt = 1e-2 as scripts/gpu_c5.sh runs it), against the ORACLE rather than as a
+    property: 16 rays (2 sources x 8 directions, grazing to diameter; 537 MB of dense oracle rows) -- end states bit for
+    bit, rho and M entry for entry, and the matrix-free loop's device passes y = M x, b = M'v, w = M'(M x), diag(M'M)
+    against the same products formed on the host from the oracle's matrix (1e-12: order-free sums)."""
+    import ray_amd
+    import scipy.sparse as sps
+    N, dt = 1024, 1e-2
+    c, tab, m = _data(orc, N, 2, 8, 1)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt, nthreads=16)
+    assert nso.max() >= 120
+    scale = float(np.max(np.abs(Mo)))
+    Mo = sps.csr_matrix(Mo)
+    med = ray_amd.GridMedium(c, 1.5, ctx)
+    F, X, rho, info = ray_amd.forward_operator_dev(med, m, 1.5, dt, ctx=ctx, droptol=None)
+    try:
+        assert np.array_equal(info["nsteps"], nso) and np.array_equal(info["status"], sto)
+        assert np.array_equal(X, Xo)
+        assert np.max(np.abs(rho - rho_o)) <= MTOL * np.max(np.abs(rho_o))
+        D = (F.tocsr() - Mo).tocoo()
+        assert (np.max(np.abs(D.data)) if D.nnz else 0.0) <= MTOL * scale
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal(N * N) * 1e-2
+        v = rng.standard_normal(4 * m.shape[0])
+        y = Mo @ x
+        ys = float(np.max(np.abs(y)))
+        assert np.max(np.abs(F.matvec(x) - y)) <= 1e-12 * ys
+        b = Mo.T @ v
+        assert np.max(np.abs(F.rmatvec(v) - b)) <= 1e-12 * float(np.max(np.abs(b)))
+        w = Mo.T @ y
+        assert np.max(np.abs(F.normal_matvec(x) - w)) <= 1e-12 * float(np.max(np.abs(w)))
+        d = np.asarray(Mo.multiply(Mo).sum(axis=0)).ravel()
+        assert np.max(np.abs(F.normal_diag() - d)) <= 1e-12 * float(np.max(d))
+    finally:
+        F.close()
