@@ -208,6 +208,12 @@ def rep_shift_fused(s0, c0, d):
     return s.value, c.value
 
 
+def rep_shift_tiny(s0, c0, d):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_rep_shift_tiny(C.c_double(s0), C.c_double(c0), C.c_double(d), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
 def anchor_period(w, dt, cmax):
     return int(lib().orc_anchor_period(C.c_double(w), C.c_double(dt), C.c_double(cmax)))
 

@@ -254,7 +254,7 @@ static double grid_speed(double x, double y, const double *eval, const double *p
  * Inside an RK4 step stages 2-4 advance the first stage's (sin, cos) by the small difference d of the
  * arguments (angle addition with Taylor sums of sin d and 1 - cos d, |d| <= 1/4; beyond: the full
  * evaluation): absolute error 1.6e-16 measured, against the 1.1e-16 of a correctly rounded value.   */
-static const double REP_BOUND = 262144.0, REP_SHIFT_MAX = 0.25;
+static const double REP_BOUND = 262144.0, REP_SHIFT_MAX = 0.25, REP_TINY_MAX = 0.0009765625;
 static void rep_kernel(double y, double t, double *sn, double *cs)
 {
     static const double S[6] = {-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
@@ -318,6 +318,15 @@ void orc_rep_shift_fused(double s0, double c0, double d, double *sn, double *cs)
     double pc = Tc[5];
     for (int k = 4; k >= 0; --k) pc = fma(z, pc, Tc[k]);
     double v = z * pc;                                            /* 1 - cos d */
+    *sn = fma(c0, sd, fma(-s0, v, s0));
+    *cs = fma(-s0, sd, fma(-c0, v, c0));
+}
+/* the advance by a tiny difference, |d| <= REP_TINY_MAX (ray_trig.h shift_tiny): sin d = d - d^3/6, 1 - cos d = d^2/2 - d^4/24 */
+void orc_rep_shift_tiny(double s0, double c0, double d, double *sn, double *cs)
+{
+    double z = d * d;
+    double sd = fma(d * z, -1.66666666666666666667e-01, d);
+    double v = z * fma(z, -4.16666666666666666667e-02, 0.5);
     *sn = fma(c0, sd, fma(-s0, v, s0));
     *cs = fma(-s0, sd, fma(-c0, v, c0));
 }
@@ -461,11 +470,13 @@ void orc_hamilton_radial(const double X[4], const orc_radial *rd, double H[4])
  * spells out the evaluation the HIP kernels use by default (ray_device.h rhs_sinprod / rhs_radial<kFused>):
  *   - sin/cos: the reproducible evaluation above; a full evaluation ANCHORS the advances of K consecutive steps
  *     (orc_anchor_period: the argument cannot leave the advance's range in K steps), every other look-up is ONE
- *     contracted advance from the anchor, argument difference d = fma(w, x, -anchor); a look-up beyond the range
+ *     contracted advance from the anchor, argument difference d = fma(w, x, -anchor) -- except that stage 3 (O(dt^2)
+ *     from stage 2) and a later step's stage 1 (O(dt^3) from the stage 4 before it) follow from the stage BEFORE them by
+ *     orc_rep_shift_tiny where the two differences are within REP_TINY_MAX of each other; a look-up beyond the range
  *     evaluates in full and -- at a first stage -- re-anchors;
  *   - speed = fma(A sx, sy, 1), tau = fma(py, py, px px), H[2:3] = ((-g) (speed tau)) (cos sin);
  *   - the RK4 combination of the gridded fused flavour: Y = fma(H, dt/2, X), Xn = fma(sum, dt RN(1/6), X).        */
-typedef struct { double base[12]; int acnt[4]; int K[4]; } trig_state;
+typedef struct { double base[12]; double prev[12]; int acnt[4]; int K[4]; } trig_state;
 static void trig_state_init(trig_state *ts, const orc_medium *med, double dt)
 {
     memset(ts, 0, sizeof *ts);
@@ -480,7 +491,7 @@ static void trig_state_init(trig_state *ts, const orc_medium *med, double dt)
         for (int k = 0; k < med->rad.K; ++k) ts->K[k] = orc_anchor_period(M_PI, dt, cmax);
     }
 }
-static void fused_stage(int stage, int anchor, double w, double x, double base[3], double *sn, double *cs)
+static void fused_stage(int stage, int anchor, double w, double x, double base[3], double prev[3], double *sn, double *cs)
 {
     if (stage == 0 && anchor) {
         double a = w * x;
@@ -489,16 +500,21 @@ static void fused_stage(int stage, int anchor, double w, double x, double base[3
         return;
     }
     double d = fma(w, x, -base[0]);
-    if (fabs(d) <= REP_SHIFT_MAX) { orc_rep_shift_fused(base[1], base[2], d, sn, cs); return; }
-    double a = w * x;
-    orc_rep_sincos(a, sn, cs);
-    if (stage == 0) { base[0] = a; base[1] = *sn; base[2] = *cs; }
+    double dl = d - prev[0];                       /* prev: the stage before (set by stages 2 and 4 only) */
+    if ((stage == 0 || stage == 2) && fabs(dl) <= REP_TINY_MAX) orc_rep_shift_tiny(prev[1], prev[2], dl, sn, cs);
+    else if (fabs(d) <= REP_SHIFT_MAX) orc_rep_shift_fused(base[1], base[2], d, sn, cs);
+    else {
+        double a = w * x;
+        orc_rep_sincos(a, sn, cs);
+        if (stage == 0) { base[0] = a; base[1] = *sn; base[2] = *cs; }
+    }
+    if (stage == 1 || stage == 3) { prev[0] = d; prev[1] = *sn; prev[2] = *cs; }
 }
-static void hamilton_sinprod_fused(const double X[4], const orc_sinprod *sp, int stage, unsigned anchor, double base[12], double H[4])
+static void hamilton_sinprod_fused(const double X[4], const orc_sinprod *sp, int stage, unsigned anchor, double base[12], double prev[12], double H[4])
 {
     double sx, cx, sy, cy;
-    fused_stage(stage, anchor & 1u, sp->wx, X[0], base, &sx, &cx);
-    fused_stage(stage, anchor & 2u, sp->wy, X[1], base + 3, &sy, &cy);
+    fused_stage(stage, anchor & 1u, sp->wx, X[0], base, prev, &sx, &cx);
+    fused_stage(stage, anchor & 2u, sp->wy, X[1], base + 3, prev + 3, &sy, &cy);
     double speed = fma(sp->A * sx, sy, 1.0);
     double tau = fma(X[3], X[3], X[2] * X[2]);
     double s2 = speed * speed, w = speed * tau;
@@ -507,7 +523,7 @@ static void hamilton_sinprod_fused(const double X[4], const orc_sinprod *sp, int
     H[2] = ((-sp->gx) * w) * (cx * sy);
     H[3] = ((-sp->gy) * w) * (sx * cy);
 }
-static void hamilton_radial_fused(const double X[4], const orc_medium *med, int stage, unsigned anchor, double base[12], double H[4])
+static void hamilton_radial_fused(const double X[4], const orc_medium *med, int stage, unsigned anchor, double base[12], double prev[12], double H[4])
 {
     const orc_radial *rd = &med->rad;
     double speed = 1.0, g0 = 0, g1 = 0;
@@ -515,7 +531,7 @@ static void hamilton_radial_fused(const double X[4], const orc_medium *med, int 
         double dx = X[0] - rd->x[k], dy = X[1] - rd->y[k];
         double r = sqrt(fma(dy, dy, dx * dx));
         double sn, cs;
-        fused_stage(stage, anchor & (1u << k), M_PI, r, base + 3 * k, &sn, &cs);
+        fused_stage(stage, anchor & (1u << k), M_PI, r, base + 3 * k, prev + 3 * k, &sn, &cs);
         double f = ((rd->a[k] * M_PI) * cs) / r;
         speed = fma(rd->a[k], sn, speed);
         g0 = fma(f, dx, g0);
@@ -540,8 +556,8 @@ static void rk4_step_analytic_fused(const orc_medium *med, double X[4], double d
     }
 #define RHS_F(P, STAGE)                                                                     \
     do {                                                                                    \
-        if (med->kind == 0) hamilton_sinprod_fused(P, &med->sp, STAGE, anchor, ts->base, H); \
-        else hamilton_radial_fused(P, med, STAGE, anchor, ts->base, H);                     \
+        if (med->kind == 0) hamilton_sinprod_fused(P, &med->sp, STAGE, anchor, ts->base, ts->prev, H); \
+        else hamilton_radial_fused(P, med, STAGE, anchor, ts->base, ts->prev, H);           \
     } while (0)
     RHS_F(X, 0);
     for (int k = 0; k < 4; ++k) { acc[k] = H[k]; Y[k] = fma(H[k], hdt, X[k]); }

@@ -104,10 +104,23 @@ def anchor_period(w, dt, cmax):
     return 64 if k >= 64.0 else (int(k) if k >= 1.0 else 1)
 
 
+REP_TINY_MAX = 0.0009765625
+
+
+def rep_shift_tiny(s0, c0, d):
+    """the advance by a tiny difference (ray_trig.h shift_tiny; ray_oracle.c orc_rep_shift_tiny)."""
+    z = d * d
+    sd = _fma(d * z, -1.66666666666666666667e-01, d)
+    v = z * _fma(z, -4.16666666666666666667e-02, 0.5)
+    return _fma(c0, sd, _fma(-s0, v, s0)), _fma(-s0, sd, _fma(-c0, v, c0))
+
+
 def fused_stage(stage, anchor, w, x, base, slot):
     """sin/cos of w x in the fused analytic flavour: a full evaluation when this step re-anchors the argument (first
-    stage only), else one contracted advance from the anchor; beyond the advance's range: in full (a first stage
-    re-anchors)."""
+    stage only), else one contracted advance from the anchor -- or, for stage 3 and a later step's stage 1, the tiny
+    advance from the stage before where the two differences from the anchor are within REP_TINY_MAX; beyond the
+    advance's range: in full (a first stage re-anchors).  base[slot] = the anchor, base[("prev", slot)] = the stage
+    before (set by stages 2 and 4)."""
     if stage == 0 and anchor:
         a = w * x
         sn, cs = rep_sincos(a)
@@ -115,12 +128,19 @@ def fused_stage(stage, anchor, w, x, base, slot):
         return sn, cs
     a0, s0, c0 = base[slot]
     d = _fma(w, x, -a0)
-    if abs(d) <= REP_SHIFT_MAX:
-        return rep_shift_fused(s0, c0, d)
-    a = w * x
-    sn, cs = rep_sincos(a)
-    if stage == 0:
-        base[slot] = (a, sn, cs)
+    pd, ps, pc = base.get(("prev", slot), (0.0, 0.0, 0.0))
+    dl = d - pd
+    if stage in (0, 2) and abs(dl) <= REP_TINY_MAX:
+        sn, cs = rep_shift_tiny(ps, pc, dl)
+    elif abs(d) <= REP_SHIFT_MAX:
+        sn, cs = rep_shift_fused(s0, c0, d)
+    else:
+        a = w * x
+        sn, cs = rep_sincos(a)
+        if stage == 0:
+            base[slot] = (a, sn, cs)
+    if stage in (1, 3):
+        base[("prev", slot)] = (d, sn, cs)
     return sn, cs
 
 

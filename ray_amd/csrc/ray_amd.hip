@@ -170,11 +170,14 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 //  - the exit bisection (up to ~55 dependent iterations) is deferred until every lane of the
 //    wavefront has left the disk and is then run by all lanes at once; the pre-exit state is
 //    parked in the output row meanwhile.
+#ifndef RAY_ANALYTIC_WAVES
+#define RAY_ANALYTIC_WAVES 4            // sin-product medium: pure VALU, dependent fp64 chains: four waves per SIMD (<= 128 VGPRs)
+#endif
 #ifndef RAY_SHOOT_WAVES
 #define RAY_SHOOT_WAVES 5
 #endif
 template <int MED, int OB, int AR, int PATH = 0>
-__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? RAY_SHOOT_WAVES : 1) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? RAY_SHOOT_WAVES : (MED == kSinProd && !PATH) ? RAY_ANALYTIC_WAVES : 1) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of

@@ -529,30 +529,47 @@ __device__ __forceinline__ double sin_rep(double a)
 // still evaluates sin/cos of its own argument w * Y, to 1 ulp of 1, one advance away from a full evaluation.
 //   kExact: the anchor is the step's own first stage (every step evaluates it in full).
 //   kFused: an anchor serves K consecutive steps (trig::anchor_period; `anchor` = the wave-uniform "this step re-anchors"
-//           bit of the argument), the difference is one fma, the advance is trig::shift_fused.  A lane whose argument
-//           has moved beyond kShiftMax evaluates in full and -- at a first stage -- re-anchors itself.
+//           bit of the argument), the difference is one fma, the advance is trig::shift_fused.  Stage 3 sits O(dt^2) from
+//           stage 2 and the next step's stage 1 O(dt^3) from stage 4: where the two differences from the anchor are
+//           within trig::kTinyMax of each other the stage follows from the stage BEFORE it by trig::shift_tiny (half the
+//           operations; never more than two advances away from a full evaluation: stages 2 and 4 always start at the
+//           anchor).  A lane whose argument has moved beyond kShiftMax evaluates in full and -- at a first stage --
+//           re-anchors itself.  Every choice is the lane's own: the oracle's scalar restatement takes the same ones.
 struct TrigBase {
     double a[kRadialMax], s[kRadialMax], c[kRadialMax];   // per argument: x and y of the sin-product, r_k of the radial sum
+    double pd[kRadialMax], ps[kRadialMax], pc[kRadialMax]; // kFused: the stage before -- its difference from the anchor, sin, cos
 };
 template <int STAGE, int AR>
-__device__ __forceinline__ void sincos_stage(double w, double x, bool anchor, double &base_a, double &base_s, double &base_c,
-                                             double &sn, double &cs)
+__device__ __forceinline__ void sincos_stage(double w, double x, bool anchor, TrigBase &tb, int k, double &sn, double &cs)
 {
+    double &base_a = tb.a[k], &base_s = tb.s[k], &base_c = tb.c[k];
     if (STAGE == 0 && (AR == kExact || anchor)) {
         const double a = w * x;
         if (trig::in_range(a)) trig::sincos_bounded(a, sn, cs);
         else { const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y; }
         base_a = a; base_s = sn; base_c = cs;
-    } else {
-        const double d = (AR == kFused) ? __builtin_fma(w, x, -base_a) : w * x - base_a;
-        if (__builtin_fabs(d) <= trig::kShiftMax) {
-            if (AR == kFused) trig::shift_fused(base_s, base_c, d, sn, cs);
-            else trig::shift(base_s, base_c, d, sn, cs);
-        } else {
+        if (AR == kFused) { tb.pd[k] = 0.0; tb.ps[k] = sn; tb.pc[k] = cs; }
+    } else if (AR == kExact) {
+        const double d = w * x - base_a;
+        if (__builtin_fabs(d) <= trig::kShiftMax) trig::shift(base_s, base_c, d, sn, cs);
+        else {
             const double a = w * x;
             const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y;
             if (STAGE == 0) { base_a = a; base_s = sn; base_c = cs; }
         }
+    } else {
+        double d = __builtin_fma(w, x, -base_a);
+        const double dl = d - tb.pd[k];
+        if ((STAGE == 0 || STAGE == 2) && __builtin_fabs(dl) <= trig::kTinyMax) {
+            trig::shift_tiny(tb.ps[k], tb.pc[k], dl, sn, cs);
+        } else if (__builtin_fabs(d) <= trig::kShiftMax) {
+            trig::shift_fused(base_s, base_c, d, sn, cs);
+        } else {
+            const double a = w * x;
+            const double2 r = sincos_rep_call(a); sn = r.x; cs = r.y;
+            if (STAGE == 0) { base_a = a; base_s = sn; base_c = cs; d = 0.0; }
+        }
+        if (STAGE == 1 || STAGE == 3) { tb.pd[k] = d; tb.ps[k] = sn; tb.pc[k] = cs; }   // read by the stage after
     }
 }
 
@@ -563,8 +580,8 @@ template <int STAGE, int AR>
 __device__ __forceinline__ void rhs_sinprod(const SinProdDev &s, const double X[4], double H[4], TrigBase &tb, unsigned anchor)
 {
     double sx, cx, sy, cy;
-    sincos_stage<STAGE, AR>(s.wx, X[0], anchor & 1u, tb.a[0], tb.s[0], tb.c[0], sx, cx);
-    sincos_stage<STAGE, AR>(s.wy, X[1], anchor & 2u, tb.a[1], tb.s[1], tb.c[1], sy, cy);
+    sincos_stage<STAGE, AR>(s.wx, X[0], anchor & 1u, tb, 0, sx, cx);
+    sincos_stage<STAGE, AR>(s.wy, X[1], anchor & 2u, tb, 1, sy, cy);
     if (AR == kFused) {
         const double speed = __builtin_fma(s.A * sx, sy, 1.0);
         const double tau = __builtin_fma(X[3], X[3], X[2] * X[2]);
@@ -605,7 +622,7 @@ __device__ __forceinline__ void rhs_radial(const RadialDev &rd, const double X[4
             const double dx = X[0] - rd.x[k], dy = X[1] - rd.y[k];
             const double r = __builtin_sqrt(AR == kFused ? __builtin_fma(dy, dy, dx * dx) : dx * dx + dy * dy);
             double sn, cs;
-            sincos_stage<STAGE, AR>(kPi, r, anchor & (1u << k), tb.a[k], tb.s[k], tb.c[k], sn, cs);
+            sincos_stage<STAGE, AR>(kPi, r, anchor & (1u << k), tb, k, sn, cs);
             const double f = ((rd.a[k] * kPi) * cs) / r;
             if (AR == kFused) {
                 speed = __builtin_fma(rd.a[k], sn, speed);

@@ -20,6 +20,8 @@ extern "C" void t_shift(const double *s0, const double *c0, const double *d, lon
 { for (long i = 0; i < n; ++i) ray::trig::shift(s0[i], c0[i], d[i], s[i], c[i]); }
 extern "C" void t_shift_fused(const double *s0, const double *c0, const double *d, long n, double *s, double *c)
 { for (long i = 0; i < n; ++i) ray::trig::shift_fused(s0[i], c0[i], d[i], s[i], c[i]); }
+extern "C" void t_shift_tiny(const double *s0, const double *c0, const double *d, long n, double *s, double *c)
+{ for (long i = 0; i < n; ++i) ray::trig::shift_tiny(s0[i], c0[i], d[i], s[i], c[i]); }
 extern "C" int t_anchor_period(double w, double dt, double cmax) { return ray::trig::anchor_period(w, dt, cmax); }
 """
 
@@ -118,6 +120,30 @@ def test_fused_shift_accuracy_and_restatements(hdr, orc):
         assert 1 <= k <= 64 and k == orc.anchor_period(w, dt, cmax)
         if w == w:
             assert k == P.anchor_period(w, dt, cmax) if w != 0.0 else k == 64
+
+
+def test_tiny_shift_accuracy_and_restatements(hdr, orc):
+    """the fused analytic flavour's advance from the stage before (|d| <= 2^-10): two advances away from a full evaluation
+    (full -> shift_fused -> shift_tiny) the result is within 3.5e-16 of the exact sin/cos of the final argument; the C
+    oracle's and the Python restatement's readings equal the header's bit for bit."""
+    import ray_oracle as P
+    rng = np.random.default_rng(22)
+    a0 = rng.uniform(-8, 8, 200000)
+    d1 = rng.uniform(-0.25, 0.25, a0.size)
+    d2 = rng.uniform(-1, 1, a0.size) * 0.0009765625
+    s0, c0 = hdr_sincos(hdr, a0)
+    s1, c1 = hdr_shift_fused(hdr, s0, c0, d1)
+    s, c = np.empty_like(d2), np.empty_like(d2)
+    hdr.t_shift_tiny(_dp(s1), _dp(c1), _dp(d2), C.c_long(d2.size), _dp(s), _dp(c))
+    if np.finfo(np.longdouble).nmant >= 63:
+        al = a0.astype(np.longdouble) + d1.astype(np.longdouble) + d2.astype(np.longdouble)
+        assert float(np.abs(s - np.sin(al)).max()) <= 3.5e-16
+        assert float(np.abs(c - np.cos(al)).max()) <= 3.5e-16
+    for i in range(0, 20000):
+        assert orc.rep_shift_tiny(float(s1[i]), float(c1[i]), float(d2[i])) == (s[i], c[i])
+    for i in range(0, 400):
+        assert P.rep_shift_tiny(float(s1[i]), float(c1[i]), float(d2[i])) == (s[i], c[i])
+    assert P.REP_TINY_MAX == 2.0 ** -10
 
 
 def test_oracle_restatement_equals_header(hdr, orc):
