@@ -85,13 +85,16 @@ int         ray_ctx_synchronize(ray_ctx *ctx);
 /* frees the device memory the context keeps between calls (ray_forward_operator's grow-only workspaces
  * and the parked CSR arrays of the last destroyed ray_frechet); the next call allocates again.        */
 int         ray_ctx_release_workspaces(ray_ctx *ctx);
-/* Arithmetic flavour of the gridded kernels (DiscreteHamilton NonObstacle.jl:30-42 + the RK4
- * combinations NonObstacle.jl:72-76,161-171).  The reference evaluates them under @fastmath, so its
- * own results are defined only up to multiply-add contraction:
- *   RAY_ARITH_EXACT  every operator one IEEE rounding in the reference's order (= un-fused code)
- *   RAY_ARITH_FUSED  multiply-adds contracted (default; ~1.5x fewer fp64 instructions; differs
- *                    from EXACT by rounding only: ~1e-12 relative on exit states, bound 1e-10)
- * Analytic media, exit/reflection bisections and the misfit are identical in both.             */
+/* Arithmetic flavour of the right-hand sides (Hamilton NonObstacle.jl:1-4, DiscreteHamilton :30-42) and the RK4
+ * combinations (:72-76,161-171).  The reference evaluates them under @fastmath, so its own results are
+ * defined only up to multiply-add contraction:
+ *   RAY_ARITH_EXACT  every operator one IEEE rounding in the reference's order (= un-fused code); analytic
+ *                    media: sin/cos of a step's first stage in full, stages 2-4 advanced from it
+ *   RAY_ARITH_FUSED  multiply-adds contracted (default; ~1.5x fewer fp64 instructions; differs from EXACT by
+ *                    rounding only: ~1e-12 relative on exit states, bound 1e-10); analytic media: one full
+ *                    sin/cos evaluation serves several steps, the stages are advanced from it
+ * Each flavour is bit-identical to the oracle's flavour of the same name.  Exit/reflection bisections and
+ * the misfit are identical in both.                                                                       */
 #define RAY_ARITH_EXACT 0
 #define RAY_ARITH_FUSED 1
 int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
