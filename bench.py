@@ -75,7 +75,7 @@ def recorded_traffic():
     return d.get("traffic_bytes_per_launch"), d.get("l2_hit_rate"), d.get("kernel_avg_ms"), src
 
 
-def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p, reps=4):
+def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p, reps=4, hmed=None):
     """The other kernels of the hot path on the driver's clock: timed in this process after the
     headline loop, HIP events around every launch (the library's counters), few launches each, clocks already warm.
     `value` / `roofline` of the line are untouched by this.  Every entry: kernel_ms (average), ray_steps per launch,
@@ -112,6 +112,16 @@ def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num
     e.update(workload="analytic SinProd(0.3,1.5pi,1.5pi), 2048x2048 rays, dt=1e-2 (k_shoot<sinprod,none>)",
              not_exited=int((status != ray_amd.ST_EXITED).sum().item()))
     out["analytic_smooth"] = e
+    # SURVEY.md section 8(d)'s secondary point: the headline sweep at dt = h/2 (453 steps per ray; same medium handle `hmed`)
+    if hmed is not None:
+        hh = 0.5 * (2 * EXT / (NGRID - 1))
+        e = timed(lambda: rdev.shoot_to_exit_dev(ctx, hmed, NS_PER_GPU, ND, hh, m.data_ptr(), num,
+                                                 status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr()), n=2)
+        e.update(workload="headline sweep at dt = h/2 (2048x2048 rays, N=512; k_shoot<grid,none>)",
+                 frac=F_STEP_GRID * e["ray_steps_per_s"] / 1e12 / FP64_VECTOR_PEAK)
+        out["grid_dt_half_h"] = e
+        timed(lambda: rdev.shoot_to_exit_dev(ctx, hmed, NS_PER_GPU, ND, DT, m.data_ptr(), num,                # m back to the dt = 1e-2 rows
+                                             status_ptr=status.data_ptr(), nsteps_ptr=nsteps.data_ptr()), n=1)
     # a9: the trajectory part of ScatterForwardOperator for the rays just shot, on a perturbed gridded model, fan hint
     c0 = np.asfortranarray([[0.85 * ray_amd.SinProd.smooth_demo()(float(x), float(y)) + 0.1 for y in p] for x in p])
     med0 = ray_amd.GridMedium(c0, EXT, ctx)
@@ -380,7 +390,7 @@ def main():
         }
         out["runtime"] = ray_amd.runtime_info()        # which HIP runtime / RCCL this process bound
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p)
+            out["secondary"] = secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num, p, hmed=med)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
