@@ -55,5 +55,10 @@ os.makedirs(dst, exist_ok=True)
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(dst, "kernel_stats.csv"), "w").write(open(f).read())
+for f in glob.glob(os.path.join(src, "stats_secondary", "**", "*kernel_stats.csv"), recursive=True):
+    open(os.path.join(dst, "kernel_stats_secondary.csv"), "w").write(open(f).read())
+for a, b in (("bench.json", "bench_under_rocprof.json"), ("bench_secondary.json", "bench_secondary_under_rocprof.json")):
+    if os.path.exists(os.path.join(src, a)):
+        open(os.path.join(dst, b), "w").write(open(os.path.join(src, a)).read())
 open(os.path.join(dst, "pmc_summary.txt"), "w").write(open(os.path.join(src, "pmc_summary.txt")).read())
 print(json.dumps(out, indent=1))
