@@ -137,6 +137,7 @@ int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
 #define RAY_OPT_TUNE_FRECHET_LDS_ROWS 7
 #define RAY_OPT_TUNE_MERGE_GRID       8
 #define RAY_OPT_TUNE_FRECHET_SLAB_MB  9
+#define RAY_OPT_TUNE_MERGE_ENTRIES 10     /* 1: the Frechet merge sorts the twelve entries of every record (the round-2 form) instead of its four stencil segments */
 int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
 /* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by
  * ray_ctx_release_workspaces / ray_ctx_destroy) and copy to / from the caller's arrays.  From pageable memory

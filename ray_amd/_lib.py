@@ -18,6 +18,7 @@ OPT_SOURCE_STRIDE = 2
 OPT_FAN_DIRECTIONS = 3
 OPT_TUNE_BLOCK_THREADS, OPT_TUNE_WAVE_DIRS, OPT_TUNE_SORT_KEY_BITS = 4, 5, 6
 OPT_TUNE_FRECHET_LDS_ROWS, OPT_TUNE_MERGE_GRID, OPT_TUNE_FRECHET_SLAB_MB = 7, 8, 9
+OPT_TUNE_MERGE_ENTRIES = 10
 
 
 class RayError(RuntimeError):

@@ -813,7 +813,7 @@ struct ray_ctx {
     int src_stride = 1;                        // RAY_OPT_SOURCE_STRIDE
     int fan_nd = 0;                            // RAY_OPT_FAN_DIRECTIONS
     // tuning / test options (RAY_OPT_TUNE_*): explicit per-context settings, never read from the environment
-    int tune_block = 256, tune_wave_dirs = 0, tune_sort_key = 0, tune_lds_rows = -1, tune_merge_grid = 0, tune_slab_mb = 0;
+    int tune_block = 256, tune_wave_dirs = 0, tune_sort_key = 0, tune_lds_rows = -1, tune_merge_grid = 0, tune_slab_mb = 0, tune_merge_entries = 0;
     // one retired set of matrix arrays (ray_frechet_destroy parks them here, the next ray_forward_operator
     // takes them back if they are large enough): the loop frees M and builds the next one every iteration
     static constexpr int kPool = 11;           // indptr, indices, data (CSR, on export) | uoff, ucols, uvals, rowcnt (block rows) | band offsets, M x (scatter passes)
@@ -2035,39 +2035,56 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     if (ctx->arith == RAY_ARITH_FUSED) hipLaunchKernelGGL(k_frechet<kFused>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
     else hipLaunchKernelGGL(k_frechet<kExact>, dim3((unsigned)nwave), dim3(64), lds, ctx->stream, a);
     HIPCHK(hipGetLastError());
-    // distinct nodes per ray
+    // distinct nodes per ray: the records' stencil segments sorted by first node (ray_frechet.h); RAY_OPT_TUNE_MERGE_ENTRIES = 1
+    // selects the older form that sorts the twelve entries of every record (kept for A/B and as a cross-check in the tests)
+    const bool by_entries = ctx->tune_merge_entries != 0;
     int n2 = 256;
-    while (n2 < frechet_entries(cap_max)) n2 <<= 1;
-    // 32-bit sort keys when node index and emission index fit together (N <= 724 at the largest n2 = 4096
-    // that leaves room, N <= 1448 at n2 <= 1024, ...); RAY_OPT_TUNE_SORT_KEY_BITS = 64 forces the wide keys
+    while (n2 < (by_entries ? frechet_entries(cap_max) : frechet_segments(cap_max))) n2 <<= 1;
+    // 32-bit sort keys when first node, id and (segments) length fit together; RAY_OPT_TUNE_SORT_KEY_BITS = 64 forces the wide ones
     int eshift = 0;
     while ((1 << eshift) < n2) ++eshift;
     const bool env_wide = ctx->tune_sort_key == 64;                      // RAY_OPT_TUNE_SORT_KEY_BITS
-    const bool narrow_key = !env_wide && eshift < 32 && (uint64_t)med->N * (uint64_t)med->N < (1ull << (32 - eshift)) - 1;
-    const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8);
-    if (narrow_key) {
-        if (sort_lds > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<kSortThreads, uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<kSortThreads, uint32_t>), dim3((unsigned)num), dim3(kSortThreads), sort_lds, ctx->stream, dcells.as<int32_t>(),
-                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
+    const int idbits = eshift + (by_entries ? 0 : 2);
+    const bool narrow_key = !env_wide && idbits < 31 && (uint64_t)med->N * (uint64_t)med->N < (1ull << (32 - idbits)) - 1;
+    const size_t sort_lds = merge_sort_lds_bytes(n2, narrow_key ? 4 : 8) + (by_entries ? 0 : 2 * (size_t)n2);
+#define RAY_LAUNCH_SORT(KERNEL)                                                                                                        \
+    do {                                                                                                                               \
+        if (sort_lds > 48 * 1024)                                                                                                      \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds)); \
+        hipLaunchKernelGGL((KERNEL), dim3((unsigned)num), dim3(kSortThreads), sort_lds, ctx->stream, dcells.as<int32_t>(),             \
+                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),    \
+                           ducnt.as<int32_t>(), eshift, med->N);                                                                      \
+    } while (0)
+    if (by_entries) {
+        if (narrow_key) RAY_LAUNCH_SORT((k_merge_sort<kSortThreads, uint32_t>));
+        else RAY_LAUNCH_SORT((k_merge_sort<kSortThreads, uint64_t>));
     } else {
-        if (sort_lds > 48 * 1024)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_merge_sort<kSortThreads, uint64_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-        hipLaunchKernelGGL((k_merge_sort<kSortThreads, uint64_t>), dim3((unsigned)num), dim3(kSortThreads), sort_lds, ctx->stream, dcells.as<int32_t>(),
-                           dsrt.as<uint32_t>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(), ducnt.as<int32_t>(), eshift, med->N);
+        if (narrow_key) RAY_LAUNCH_SORT((k_seg_sort<kSortThreads, uint32_t>));
+        else RAY_LAUNCH_SORT((k_seg_sort<kSortThreads, uint64_t>));
     }
+#undef RAY_LAUNCH_SORT
     HIPCHK(hipGetLastError());
     if ((rc = scan_counts(ctx, ducnt.as<int32_t>(), num, f->uoff(), &f->U))) return rc;
     HIPCHK(frechet_alloc(f, kFmUcols, sizeof(int32_t) * (size_t)(f->U ? f->U : 1)));
     HIPCHK(frechet_alloc(f, kFmUvals, sizeof(double) * 4 * (size_t)(f->U ? f->U : 1)));
-    // the ray's records sit in LDS during the merge when they fit (42 KiB = 224 rows of 144 + 48 B; RAY_OPT_TUNE_FRECHET_LDS_ROWS for the tests)
+    // the ray's records sit in LDS during the merge when they fit (224 rows of 144 B; RAY_OPT_TUNE_FRECHET_LDS_ROWS for the tests)
     int lds_rows = std::min(frechet_rows(cap_max), kMergeLdsMaxRows);
     if (ctx->tune_lds_rows >= 0) lds_rows = std::min(lds_rows, ctx->tune_lds_rows);
     // one workgroup per ray; RAY_OPT_TUNE_MERGE_GRID (tests, experiments) makes fewer workgroups loop over the rays instead
     const int64_t emit_grid = ctx->tune_merge_grid > 0 ? std::min<int64_t>(num, ctx->tune_merge_grid) : num;
-    hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes, ctx->stream,
-                       dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),
-                       drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
+    if (by_entries) {
+        hipLaunchKernelGGL(k_merge_emit, dim3((unsigned)emit_grid), dim3(256), (size_t)lds_rows * kMergeLdsRowBytes, ctx->stream,
+                           dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),
+                           drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
+    } else {
+        const int max_rows = frechet_rows(cap_max);
+        const size_t emit_lds = seg_emit_lds_bytes(lds_rows, max_rows);
+        if (emit_lds > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));
+        hipLaunchKernelGGL(k_seg_emit, dim3((unsigned)emit_grid), dim3(256), emit_lds, ctx->stream,
+                           dsrt.as<uint32_t>(), dtraj.as<double>(), dbase.as<int64_t>(), dcap.as<int32_t>(), dperm.as<int32_t>(), ob_.ns.as<int32_t>(),
+                           drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, max_rows, num, f->ucols(), f->uvals(), f->rowcnt());
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(frechet_alloc(f, kFmIndptr, sizeof(int64_t) * (size_t)(4 * num + 1)));
     if ((rc = scan_counts(ctx, f->rowcnt(), 4 * num, f->indptr(), &f->nnz))) return rc;
@@ -2653,6 +2670,7 @@ int ray_ctx_set_option(ray_ctx *ctx, int option, int value)
     if (option == RAY_OPT_TUNE_FRECHET_LDS_ROWS) { ctx->tune_lds_rows = value < 0 ? -1 : value; return RAY_OK; }
     if (option == RAY_OPT_TUNE_MERGE_GRID) { ctx->tune_merge_grid = value < 0 ? 0 : value; return RAY_OK; }
     if (option == RAY_OPT_TUNE_FRECHET_SLAB_MB) { ctx->tune_slab_mb = value < 0 ? 0 : value; return RAY_OK; }
+    if (option == RAY_OPT_TUNE_MERGE_ENTRIES) { ctx->tune_merge_entries = value != 0; return RAY_OK; }
     return fail(RAY_ERR_INVALID, "unknown option");
 }
 

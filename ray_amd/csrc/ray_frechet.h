@@ -686,13 +686,19 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
 // Theta column of emission e = 12 row + k from the ray's trajectory records (see kTrajDoubles)
 // (`stride`: doubles between consecutive records: kTrajDoubles in the slab, kTrajLdsDoubles in the LDS copy)
 constexpr int kTrajLdsDoubles = kTrajDoubles + 2;      // 144-byte rows: records of different rows on different banks
+__device__ __forceinline__ void theta_of_record(const double2 *__restrict__ rec, unsigned k, double th[4]);
 __device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, int stride, unsigned e, int N, double th[4], int &node)
 {
     const unsigned r = (e * 43691u) >> 19, k = e - r * (unsigned)kFrSlotsPerCall;
     const double2 *rec = reinterpret_cast<const double2 *>(recs + (size_t)r * stride);
-    const double2 uv = rec[6];
     const int cv = (int)__double_as_longlong(rec[7].x);
     node = ((cv & 0xffff) + stencil_di((int)k)) + ((cv >> 16) + stencil_dj((int)k)) * N;
+    theta_of_record(rec, k, th);
+}
+// Theta column of stencil node k from one trajectory record
+__device__ __forceinline__ void theta_of_record(const double2 *__restrict__ rec, unsigned k, double th[4])
+{
+    const double2 uv = rec[6];
     const double u = uv.x, v = uv.y, a = 1 - u, b = 1 - v;
     const unsigned kk = k & 3u;
     // t = {ab, ub, av, uv}: phi_kk = t[kk], psi_kk = +-t[kk ^ 1] (minus for odd kk), gam_kk = +-t[kk ^ 2] (minus for kk >= 2)
@@ -853,6 +859,407 @@ __global__ __launch_bounds__(256) void k_merge_emit(const uint32_t *__restrict__
     if (tid < 4) rowcnt[ray * 4 + tid] = s_rows[tid];
     __syncthreads();
     RAY_FR_MARK(4);
+    }
+}
+
+// ---- merge by stencil SEGMENTS ---------------------------------------------------------------------------
+// In node order (i + j N) the twelve stencil nodes of a cell (i, j) are four runs of consecutive nodes: row j - 1:
+// i, i + 1; rows j and j + 1: i - 1 .. i + 2; row j + 2: i, i + 1.  Sorting the 4 segments of every record by their
+// first node -- a third of the keys, a quarter of the network at the usual sizes -- orders everything the merge needs:
+// a segment OWNS the nodes it covers that no earlier segment (in sorted order) reaches, owned nodes come out in
+// increasing order, and the other contributions to an owned node sit in the segments right behind its owner.
+//   k_seg_sort   keys (first node, record * 4 + segment, length - 1); the network of k_merge_sort; the number of
+//                distinct nodes of the ray = what the segments own; hands over the sorted segment ids (2 bytes each)
+//   k_seg_emit   records and sorted ids in LDS; first node and length of every segment from its record's cell; the
+//                running maximum of the ends and the owned counts scanned over the workgroup; then every thread
+//                walks its stretch of segments: each owned node sums its contributions (sorted order: first node,
+//                then emission), applies rho, writes column and values.
+// Segments are clipped to the grid (a cell on the grid's rim); a segment wholly outside is dead and sorts last.
+constexpr uint16_t kSegDead = 0xffffu;
+__host__ __device__ inline int frechet_segments(int steps) { return frechet_rows(steps) * 4; }
+
+__device__ __forceinline__ void stencil_segment(int cv, int sg, int N, int &start, int &len, int &di0)
+{
+    const int i = cv & 0xffff, j = cv >> 16;
+    const int row = j - 1 + sg;
+    const bool wide = sg == 1 || sg == 2;
+    const int lo = wide ? i - 1 : i, hi = wide ? i + 2 : i + 1;
+    di0 = lo - i;
+    const int clo = lo > 0 ? lo : 0, chi = hi < N - 1 ? hi : N - 1;
+    len = ((unsigned)row < (unsigned)N && chi >= clo) ? chi - clo + 1 : 0;
+    start = clo + row * N;
+}
+// stencil index k of the node at x-offset di (-1 .. 2) in segment sg: a nibble table (see stencil_di / stencil_dj)
+__device__ __forceinline__ unsigned stencil_k_of(int sg, int di)
+{
+    return (unsigned)(0x0980632741050ba0ull >> (4 * (sg * 4 + di + 1))) & 15u;
+}
+
+template <typename K> struct SegKey;
+template <> struct SegKey<uint64_t> {
+    static __device__ __forceinline__ uint64_t dead() { return kKeyDead; }
+    static __device__ __forceinline__ uint64_t pack(int start, int q, int len, int) { return (uint64_t)start << 40 | (uint64_t)q << 20 | (uint64_t)(len - 1); }
+    static __device__ __forceinline__ int start(uint64_t k, int) { return (int)(k >> 40); }
+    static __device__ __forceinline__ int q(uint64_t k, int) { return (int)(k >> 20) & 0xFFFFF; }
+    static __device__ __forceinline__ int len(uint64_t k) { return (int)(k & 3u) + 1; }
+};
+template <> struct SegKey<uint32_t> {                 // first node << (es + 2) | id << 2 | length - 1
+    static __device__ __forceinline__ uint32_t dead() { return 0xffffffffu; }
+    static __device__ __forceinline__ uint32_t pack(int start, int q, int len, int es) { return (uint32_t)start << (es + 2) | (uint32_t)q << 2 | (uint32_t)(len - 1); }
+    static __device__ __forceinline__ int start(uint32_t k, int es) { return (int)(k >> (es + 2)); }
+    static __device__ __forceinline__ int q(uint32_t k, int es) { return (int)(k >> 2) & ((1 << es) - 1); }
+    static __device__ __forceinline__ int len(uint32_t k) { return (int)(k & 3u) + 1; }
+};
+
+// the bitonic network of k_merge_sort on n2 keys in LDS whose aligned groups of sixteen are sorted already
+template <int BT, typename K>
+__device__ __forceinline__ void bitonic_from_sixteen(K *sk, int n2, int tid)
+{
+    auto spad = [](int i) { return i + (i >> 4); };
+    const int ngroup = n2 >> 4;
+    for (int top0 = 4; (1 << top0) < n2; ++top0) {
+        {
+            const int b = top0 - 3, lm = (1 << b) - 1;
+            unsigned d[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
+            for (int t = tid; t < ngroup; t += BT) {
+                const int hi = (t >> b) << (b + 4), lo = t & lm;
+                const unsigned a_lo = (unsigned)sizeof(K) * (unsigned)spad(hi | lo), a_hi = (unsigned)sizeof(K) * (unsigned)spad(hi | (lo ^ lm));
+                char *base = reinterpret_cast<char *>(sk);
+                K v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<K *>(base + (j < 8 ? a_lo : a_hi) + d[j]);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) cmp_exchange<K>(v[p], v[15 - p]);
+                sort_group_strides<K>(v, 3);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) *reinterpret_cast<K *>(base + (j < 8 ? a_lo : a_hi) + d[j]) = v[j];
+            }
+            __syncthreads();
+        }
+        for (int top = top0 - 4; top >= 0;) {
+            const int b = top >= 3 ? top - 3 : 0;
+            unsigned d[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[j] = (unsigned)sizeof(K) * (unsigned)spad(j << b);
+            for (int t = tid; t < ngroup; t += BT) {
+                const unsigned a0 = (unsigned)sizeof(K) * (unsigned)spad(((t >> b) << (b + 4)) | (t & ((1 << b) - 1)));
+                char *base = reinterpret_cast<char *>(sk);
+                K v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<K *>(base + a0 + d[j]);
+                sort_group_strides<K>(v, top - b + 1);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) *reinterpret_cast<K *>(base + a0 + d[j]) = v[j];
+            }
+            __syncthreads();
+            top = b - 1;
+        }
+    }
+}
+
+// exclusive scans over the threads of a workgroup (BT / 64 waves): running maximum and running sum of one int each
+template <int BT>
+__device__ __forceinline__ int block_excl_max(int v, int *s_w, int tid)        // identity 0 (the values are >= 0)
+{
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl = incl > o ? incl : o;
+    }
+    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) { const int c = s_w[w]; if (w < (tid >> 6)) before = before > c ? before : c; }
+    int excl = __shfl_up(incl, 1, 64);
+    if ((tid & 63) == 0) excl = 0;
+    excl = excl > before ? excl : before;
+    __syncthreads();
+    return excl;
+}
+template <int BT>
+__device__ __forceinline__ int block_excl_sum(int v, int *s_w, int tid, int &total)
+{
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if ((tid & 63) >= off) incl += o;
+    }
+    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) { const int c = s_w[w]; before += w < (tid >> 6) ? c : 0; total += c; }
+    __syncthreads();
+    return before + incl - v;
+}
+
+template <int BT, typename K>
+__global__ __launch_bounds__(BT) void k_seg_sort(const int32_t *__restrict__ cells, uint32_t *__restrict__ srt,
+                                                  const int64_t *__restrict__ wave_base,
+                                                  const int32_t *__restrict__ wave_cap, const int32_t *__restrict__ perm,
+                                                  const int32_t *__restrict__ nsteps, int32_t *__restrict__ ucount, int eshift, int N)
+{
+    typedef SegKey<K> SK;
+    auto spad = [](int i) { return i + (i >> 4); };
+    K *sk = reinterpret_cast<K *>(ray_smem);
+    __shared__ int s_w[BT / 64];
+    __shared__ int s_cell[kMergeMaxEntries / kFrSlotsPerCall + 4];
+    const int tid = threadIdx.x;
+    const int64_t slot = blockIdx.x;
+    const int64_t ray = perm[slot];
+    const int nrow = frechet_rows(nsteps[ray]);
+    const int nseg = nrow * 4;
+    if (nseg == 0) {
+        if (tid == 0) ucount[ray] = 0;
+        return;
+    }
+    int n2 = 256;
+    while (n2 < nseg) n2 <<= 1;
+    const int64_t wb = wave_base[slot >> 6];
+    const int lane = (int)(slot & 63);
+    uint16_t *rk = reinterpret_cast<uint16_t *>(srt + ray_row0(wb, wave_cap[slot >> 6], lane) * kFrSlotsPerCall);
+    for (int r = tid; r < nrow + 3; r += BT) s_cell[r] = r < nrow ? cells[(wb + r) * 64 + lane] : 0;
+    __syncthreads();
+    const int ngroup = n2 >> 4;
+    for (int t = tid; t < ngroup; t += BT) {                       // sixteen keys = the segments of four records
+        K v[16];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * t + rr;
+            const int cv = r < nrow ? s_cell[r] : 0;
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                int start, len, di0;
+                stencil_segment(cv, sg, N, start, len, di0);
+                v[4 * rr + sg] = (r < nrow && len > 0) ? SK::pack(start, 4 * r + sg, len, eshift) : SK::dead();
+            }
+        }
+        sort_sixteen<K>(v);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sk[t * 17 + j] = v[j];
+    }
+    __syncthreads();
+    bitonic_from_sixteen<BT, K>(sk, n2, tid);
+    // what the segments own: a node is new when no earlier segment reaches it (running maximum of the ends)
+    const int cs = n2 / BT, e0 = tid * cs;
+    int mx = 0;
+    for (int e = e0; e < e0 + cs; ++e) {
+        const K k = sk[spad(e)];
+        if (k != SK::dead()) { const int en = SK::start(k, eshift) + SK::len(k); mx = mx > en ? mx : en; }
+    }
+    int pme = block_excl_max<BT>(mx, s_w, tid);
+    int own = 0;
+    for (int e = e0; e < e0 + cs; ++e) {
+        const K k = sk[spad(e)];
+        if (k != SK::dead()) {
+            const int st = SK::start(k, eshift), en = st + SK::len(k);
+            const int a = st > pme ? st : pme;
+            own += en > a ? en - a : 0;
+            pme = pme > en ? pme : en;
+        }
+    }
+    int total;
+    (void)block_excl_sum<BT>(own, s_w, tid, total);
+    if (tid == 0) ucount[ray] = total;
+    // the sorted ids leave through LDS (a stretch of its own behind the launch's key capacity 2^eshift), consecutive
+    // lanes on consecutive halfwords
+    uint16_t *sw = reinterpret_cast<uint16_t *>(ray_smem + merge_sort_lds_bytes(1 << eshift, sizeof(K)));
+    for (int e = e0; e < e0 + cs; ++e) {
+        const K k = sk[spad(e)];
+        sw[e] = k != SK::dead() ? (uint16_t)SK::q(k, eshift) : kSegDead;
+    }
+    __syncthreads();
+    for (int e = tid; e < nseg; e += BT) rk[e] = sw[e];
+}
+
+
+#ifndef RAY_SEG_WINDOW
+#define RAY_SEG_WINDOW 4
+#endif
+constexpr int kSegWindow = RAY_SEG_WINDOW;                                     // segments behind an owner looked at without a loop
+constexpr int kSegLdsRowBytes = kTrajLdsDoubles * 8;             // the record copy; + 48 B per row of the longest ray for the segments
+__host__ __device__ inline size_t seg_emit_lds_bytes(int lds_rows, int max_rows)
+{
+    return (size_t)lds_rows * kSegLdsRowBytes + (size_t)max_rows * (4 * 4 + 4 * 2 + kFrSlotsPerCall * 2) + 16;
+}
+// Theta column of node n as segment (id q: record q >> 2, stencil segment q & 3) sees it
+__device__ __forceinline__ void theta_of_segment_node(const double *__restrict__ recs, int stride, unsigned q, int n, int N, double th[4])
+{
+    const int sg = (int)(q & 3u);
+    const double2 *rec = reinterpret_cast<const double2 *>(recs + (size_t)(q >> 2) * stride);
+    const int cv = (int)__double_as_longlong(rec[7].x);
+    const int di = n - (int)mad24((unsigned)((cv >> 16) - 1 + sg), (unsigned)N, (unsigned)(cv & 0xffff));
+    theta_of_record(rec, stencil_k_of(sg, di), th);
+}
+__global__ __launch_bounds__(256) void k_seg_emit(const uint32_t *__restrict__ srt, const double *__restrict__ traj,
+                                                  const int64_t *__restrict__ wave_base, const int32_t *__restrict__ wave_cap,
+                                                  const int32_t *__restrict__ perm, const int32_t *__restrict__ nsteps,
+                                                  const double *__restrict__ rho, const int64_t *__restrict__ uoff,
+                                                  double droptol, int N, int lds_rows, int max_rows, int64_t num, int32_t *__restrict__ ucols,
+                                                  double *__restrict__ uvals, int32_t *__restrict__ rowcnt)
+{
+    __shared__ int s_rows[4];
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x;
+    // per sorted segment: first node << 3 | length (length 0: dead) and its id; per distinct node, in node order: its owner
+    // (sorted index of the first segment that reaches it) << 2 | its offset in that segment
+    uint32_t *s_seg = reinterpret_cast<uint32_t *>(ray_smem + (size_t)lds_rows * kSegLdsRowBytes);
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_seg + (size_t)max_rows * 4);
+    uint16_t *s_own = s_q + (size_t)max_rows * 4;
+    constexpr uint32_t kDeadSeg = 0xfffffff8u;
+    for (int64_t slot = blockIdx.x; slot < num; slot += gridDim.x) {
+    const int64_t ray = perm[slot];
+    if (tid < 4) s_rows[tid] = 0;
+    const int nrow = frechet_rows(nsteps[ray]);
+    const int nseg = nrow * 4;
+    const int64_t row0 = ray_row0(wave_base[slot >> 6], wave_cap[slot >> 6], (int)(slot & 63));
+    const uint16_t *rk = reinterpret_cast<const uint16_t *>(srt + row0 * kFrSlotsPerCall);
+    const double *recs_g = traj + row0 * kTrajDoubles;
+    const int64_t off = uoff[ray];
+    double R[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) R[k] = rho[ray * 16 + k];
+    const bool in_lds = nrow <= lds_rows;
+    if (in_lds) {
+        // every load of the copy is issued before the first one is waited for (fixed trip counts)
+        double2 *l2 = reinterpret_cast<double2 *>(ray_smem);
+        const double2 *g2 = reinterpret_cast<const double2 *>(recs_g);
+        constexpr int kRecLoads = kMergeLdsMaxRows * (kTrajDoubles / 2) / 256, kIdLoads = (kMergeLdsMaxRows * 2 + 255) / 256;
+        double2 rv[kRecLoads];
+        uint32_t wv[kIdLoads];
+        const int nrec2 = nrow * (kTrajDoubles / 2), nid2 = nrow * 2;          // ids two by two (a row's four are 8 bytes)
+        const uint32_t *rk2 = reinterpret_cast<const uint32_t *>(rk);
+#pragma unroll
+        for (int k = 0; k < kRecLoads; ++k) rv[k] = tid + 256 * k < nrec2 ? g2[tid + 256 * k] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < kIdLoads; ++k) wv[k] = tid + 256 * k < nid2 ? rk2[tid + 256 * k] : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < kRecLoads; ++k) {
+            const int q = tid + 256 * k;
+            if (q < nrec2) l2[(q >> 3) * (kTrajLdsDoubles / 2) + (q & 7)] = rv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kIdLoads; ++k)
+            if (tid + 256 * k < nid2) reinterpret_cast<uint32_t *>(s_q)[tid + 256 * k] = wv[k];
+    } else {
+        for (int e = tid; e < nseg; e += 256) s_q[e] = rk[e];
+    }
+    __syncthreads();
+    const double *recs = in_lds ? reinterpret_cast<const double *>(ray_smem) : recs_g;
+    const int stride = in_lds ? kTrajLdsDoubles : kTrajDoubles;
+    // first node and length of every sorted segment, from its record's cell
+    for (int e = tid; e < nseg; e += 256) {
+        const unsigned q = s_q[e];
+        uint32_t w = kDeadSeg;
+        if (q != kSegDead) {
+            const int cv = (int)__double_as_longlong(recs[(size_t)(q >> 2) * stride + 14]);
+            int start, len, di0;
+            stencil_segment(cv, (int)(q & 3u), N, start, len, di0);
+            if (len > 0) w = (uint32_t)start << 3 | (uint32_t)len;
+        }
+        s_seg[e] = w;
+    }
+    __syncthreads();
+    // what every segment owns: the nodes no earlier segment reaches (running maximum of the ends), ranked by a running sum
+    const int cs = (nseg + 255) / 256, e0 = tid * cs < nseg ? tid * cs : nseg, e1 = e0 + cs < nseg ? e0 + cs : nseg;
+    int mx = 0;
+    for (int e = e0; e < e1; ++e) {
+        const uint32_t w = s_seg[e];
+        const int en = (int)(w >> 3) + (int)(w & 7u);
+        if (w & 7u) mx = mx > en ? mx : en;
+    }
+    const int pme = block_excl_max<256>(mx, s_w, tid);
+    int own = 0;
+    {
+        int pm = pme;
+        for (int e = e0; e < e1; ++e) {
+            const uint32_t w = s_seg[e];
+            if (w & 7u) {
+                const int st = (int)(w >> 3), en = st + (int)(w & 7u);
+                const int a = st > pm ? st : pm;
+                own += en > a ? en - a : 0;
+                pm = pm > en ? pm : en;
+            }
+        }
+    }
+    int total;
+    int rank = block_excl_sum<256>(own, s_w, tid, total);
+    {
+        int pm = pme;
+        for (int e = e0; e < e1; ++e) {
+            const uint32_t w = s_seg[e];
+            if (w & 7u) {
+                const int st = (int)(w >> 3), en = st + (int)(w & 7u);
+                for (int n = st > pm ? st : pm; n < en; ++n) s_own[rank++] = (uint16_t)(e << 2 | (n - st));
+                pm = pm > en ? pm : en;
+            }
+        }
+    }
+    __syncthreads();
+    // one distinct node per thread, in node order: its owner's Theta column and those of the segments right behind it
+    int cnt[4] = {0, 0, 0, 0};
+    for (int x = tid; x < total; x += 256) {
+        const unsigned ow = s_own[x];
+        const int js = (int)(ow >> 2);
+        const uint32_t w = s_seg[js];
+        const int n = (int)(w >> 3) + (int)(ow & 3u);
+        uint32_t wn[kSegWindow];
+#pragma unroll
+        for (int t = 0; t < kSegWindow; ++t) wn[t] = js + 1 + t < nseg ? s_seg[js + 1 + t] : kDeadSeg;
+        double s4[4];
+        theta_of_segment_node(recs, stride, s_q[js], n, N, s4);
+        bool more = true;
+        unsigned cover = 0;                                           // which of the window's segments reach n
+#pragma unroll
+        for (int t = 0; t < kSegWindow; ++t) {
+            const int sj = (int)(wn[t] >> 3);
+            more = more && sj <= n;
+            cover |= (unsigned)(more && sj + (int)(wn[t] & 7u) > n) << t;
+        }
+        while (cover) {                                               // in sorted order; as many passes as the busiest lane needs
+            const int t = __builtin_ctz(cover);
+            cover &= cover - 1;
+            double th[4];
+            theta_of_segment_node(recs, stride, s_q[js + 1 + t], n, N, th);
+            s4[0] += th[0]; s4[1] += th[1]; s4[2] += th[2]; s4[3] += th[3];              // Phi += Theta (:159,175)
+        }
+        for (int j = js + 1 + kSegWindow; more && j < nseg; ++j) {        // rare: more than kSegWindow segments start within reach
+            const uint32_t wj = s_seg[j];
+            const int sj = (int)(wj >> 3);
+            if (sj > n) break;
+            if (sj + (int)(wj & 7u) <= n) continue;
+            double th[4];
+            theta_of_segment_node(recs, stride, s_q[j], n, N, th);
+            s4[0] += th[0]; s4[1] += th[1]; s4[2] += th[2]; s4[3] += th[3];
+        }
+        double o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
+            o4[i] = ((R[i * 4] * s4[0] + R[i * 4 + 1] * s4[1]) + R[i * 4 + 2] * s4[2]) + R[i * 4 + 3] * s4[3];
+            cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);                    // droptol! (:242)
+        }
+        const int64_t u = off + x;
+        ucols[u] = (int32_t)n;
+        double2 *dst = reinterpret_cast<double2 *>(uvals + u * 4);
+        dst[0] = make_double2(o4[0], o4[1]);
+        dst[1] = make_double2(o4[2], o4[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = cnt[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if ((tid & 63) == 0 && c) atomicAdd(&s_rows[i], c);
+    }
+    __syncthreads();
+    if (tid < 4) rowcnt[ray * 4 + tid] = s_rows[tid];
+    __syncthreads();
     }
 }
 
