@@ -959,27 +959,7 @@ __device__ __forceinline__ void bitonic_from_sixteen(K *sk, int n2, int tid)
     }
 }
 
-// exclusive scans over the threads of a workgroup (BT / 64 waves): running maximum and running sum of one int each
-template <int BT>
-__device__ __forceinline__ int block_excl_max(int v, int *s_w, int tid)        // identity 0 (the values are >= 0)
-{
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        if ((tid & 63) >= off) incl = incl > o ? incl : o;
-    }
-    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w = 0; w < BT / 64; ++w) { const int c = s_w[w]; if (w < (tid >> 6)) before = before > c ? before : c; }
-    int excl = __shfl_up(incl, 1, 64);
-    if ((tid & 63) == 0) excl = 0;
-    excl = excl > before ? excl : before;
-    __syncthreads();
-    return excl;
-}
+// exclusive running sum of one int over the threads of a workgroup (BT / 64 waves)
 template <int BT>
 __device__ __forceinline__ int block_excl_sum(int v, int *s_w, int tid, int &total)
 {
@@ -1046,14 +1026,24 @@ __global__ __launch_bounds__(BT) void k_seg_sort(const int32_t *__restrict__ cel
     }
     __syncthreads();
     bitonic_from_sixteen<BT, K>(sk, n2, tid);
-    // what the segments own: a node is new when no earlier segment reaches it (running maximum of the ends)
+    // what the segments own: a node is new when no earlier segment reaches it.  The running maximum of the ends needs no
+    // scan over the workgroup: a segment is at most four nodes long, so only those that start within three nodes of this
+    // stretch's first can reach into it -- a short look-back.
     const int cs = n2 / BT, e0 = tid * cs;
-    int mx = 0;
-    for (int e = e0; e < e0 + cs; ++e) {
-        const K k = sk[spad(e)];
-        if (k != SK::dead()) { const int en = SK::start(k, eshift) + SK::len(k); mx = mx > en ? mx : en; }
+    int pme = 0;
+    {
+        const K k0 = sk[spad(e0)];
+        if (k0 != SK::dead()) {
+            const int lim = SK::start(k0, eshift) - 3;
+            for (int e = e0 - 1; e >= 0; --e) {
+                const K k = sk[spad(e)];
+                const int st = SK::start(k, eshift);
+                if (st < lim) break;
+                const int en = st + SK::len(k);
+                pme = pme > en ? pme : en;
+            }
+        }
     }
-    int pme = block_excl_max<BT>(mx, s_w, tid);
     int own = 0;
     for (int e = e0; e < e0 + cs; ++e) {
         const K k = sk[spad(e)];
@@ -1166,15 +1156,20 @@ __global__ __launch_bounds__(256) void k_seg_emit(const uint32_t *__restrict__ s
         s_seg[e] = w;
     }
     __syncthreads();
-    // what every segment owns: the nodes no earlier segment reaches (running maximum of the ends), ranked by a running sum
+    // what every segment owns: the nodes no earlier segment reaches (running maximum of the ends: a look-back over the
+    // segments that start within three nodes, as in k_seg_sort), ranked by a running sum
     const int cs = (nseg + 255) / 256, e0 = tid * cs < nseg ? tid * cs : nseg, e1 = e0 + cs < nseg ? e0 + cs : nseg;
-    int mx = 0;
-    for (int e = e0; e < e1; ++e) {
-        const uint32_t w = s_seg[e];
-        const int en = (int)(w >> 3) + (int)(w & 7u);
-        if (w & 7u) mx = mx > en ? mx : en;
+    int pme = 0;
+    if (e0 < e1 && (s_seg[e0] & 7u)) {
+        const int lim = (int)(s_seg[e0] >> 3) - 3;
+        for (int e = e0 - 1; e >= 0; --e) {
+            const uint32_t w = s_seg[e];
+            const int st = (int)(w >> 3);
+            if (st < lim) break;
+            const int en = st + (int)(w & 7u);
+            pme = pme > en ? pme : en;
+        }
     }
-    const int pme = block_excl_max<256>(mx, s_w, tid);
     int own = 0;
     {
         int pm = pme;

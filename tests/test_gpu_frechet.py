@@ -202,7 +202,7 @@ class tuned:
     def __init__(self, ctx, **kv):
         from ray_amd import _lib
         self.ctx, self.kv, self.lib = ctx, kv, _lib
-        self.defaults = {"FRECHET_SLAB_MB": 0, "FRECHET_LDS_ROWS": -1, "MERGE_GRID": 0, "SORT_KEY_BITS": 0}
+        self.defaults = {"FRECHET_SLAB_MB": 0, "FRECHET_LDS_ROWS": -1, "MERGE_GRID": 0, "SORT_KEY_BITS": 0, "MERGE_ENTRIES": 0}
 
     def __enter__(self):
         for k, v in self.kv.items():
@@ -431,3 +431,49 @@ def test_config5_grid_operator_and_normal_passes_vs_oracle(ctx, orc):
         assert np.max(np.abs(F.normal_diag() - d)) <= 1e-12 * float(np.max(d))
     finally:
         F.close()
+
+
+def test_merge_by_segments_equals_merge_by_entries(ctx, orc):
+    """The merge sorts the four stencil SEGMENTS of every record (k_seg_sort / k_seg_emit); the round-2 form that sorts the
+    twelve entries (RAY_OPT_TUNE_MERGE_ENTRIES = 1: k_merge_sort / k_merge_emit) is kept as a cross-check: same pattern,
+    same values up to the order of the sums -- short rays, long rays read in place, wide keys, and the oracle beside both."""
+    import ray_amd
+    for N, ns, nd, dt, bump, lds in ((61, 6, 40, 2e-2, 0.3, -1), (31, 3, 8, 2e-3, 0.0, -1), (75, 3, 70, 2e-2, 0.3, 20)):
+        c, tab, m = _data(orc, N, ns, nd, 1, bump=bump)
+        med = ray_amd.GridMedium(c, 1.5, ctx)
+        with tuned(ctx, FRECHET_LDS_ROWS=lds):
+            M1, s1, i1 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+            with tuned(ctx, MERGE_ENTRIES=1):
+                M2, s2, i2 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+            with tuned(ctx, SORT_KEY_BITS=64):
+                M3, s3, i3 = ray_amd.ScatterForwardOperator(med, m, 1.5, dt, ctx=ctx, info=True, droptol=None)
+        assert np.array_equal(M1.indptr, M2.indptr) and np.array_equal(M1.indices, M2.indices) and np.array_equal(s1, s2)
+        assert np.max(np.abs(M1.data - M2.data)) <= 1e-13 * np.max(np.abs(M2.data))
+        assert np.array_equal(M1.indptr, M3.indptr) and np.array_equal(M1.indices, M3.indices) and np.array_equal(M1.data, M3.data)
+        Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+        assert np.max(np.abs(M1.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
+
+
+@pytest.mark.parametrize("entries", [0, 1])
+def test_forward_operator_on_the_grid_rim(ctx, orc, arith, entries):
+    """ext = 1: the unit circle touches the grid's rim, rays start in the cells i = 0 / j = 0 whose stencils reach one node
+    outside the grid (I - 1 < 1: the reference's sparse() would throw there).  Oracle and kernels drop those entries and flag
+    the ray: same matrix, same flags -- the merge's clipped and dead segments."""
+    import ray_amd
+    N, ns, nd, dt = 21, 16, 6, 2e-2
+    c = orc.sinprod_grid(orc.SMOOTH_DEMO, N, 1.0)
+    tab = orc.GridTables(c, 1.0, arith)
+    m, *_ = orc.scatter_relation(orc.SMOOTH_DEMO, ns, nd, 1e-2)
+    m = np.asfortranarray(m)
+    Xo, rho_o, Mo, sto, nso = orc.forward_operator(tab, m, dt)
+    assert (sto != 0).any()
+    med = ray_amd.GridMedium(c, 1.0, ctx)
+    ctx.set_arith(arith)
+    try:
+        with tuned(ctx, MERGE_ENTRIES=entries):
+            M, s, info = ray_amd.ScatterForwardOperator(med, m, 1.0, dt, ctx=ctx, info=True, droptol=None)
+    finally:
+        ctx.set_arith(ray_amd.ARITH_FUSED)
+    assert np.array_equal(info["nsteps"], nso) and np.array_equal(info["status"], sto)
+    assert np.array_equal(s[:, 4:8], Xo)
+    assert np.max(np.abs(M.toarray() - Mo)) <= MTOL * np.max(np.abs(Mo))
