@@ -130,14 +130,16 @@ int         ray_ctx_set_arith(ray_ctx *ctx, int arith);
  *                                SORT_KEY_BITS 0 (automatic) | 64         key width of the Frechet merge's sort
  *                                FRECHET_LDS_ROWS -1 (default) | n        longest ray whose records the merge keeps in LDS
  *                                MERGE_GRID 0 (one per ray) | n           workgroups of the merge's emit kernel
- *                                FRECHET_SLAB_MB 0 (a quarter of free memory) | n   trajectory slab budget per chunk of rays */
+ *                                FRECHET_SLAB_MB 0 (a quarter of free memory) | n   trajectory slab budget per chunk of rays
+ *                                MERGE_ENTRIES 0 (default) | 1            1: the Frechet merge sorts the twelve entries of every record
+ *                                                                         (round-2 form, kept as a cross-check) instead of its four segments */
 #define RAY_OPT_TUNE_BLOCK_THREADS    4
 #define RAY_OPT_TUNE_WAVE_DIRS        5
 #define RAY_OPT_TUNE_SORT_KEY_BITS    6
 #define RAY_OPT_TUNE_FRECHET_LDS_ROWS 7
 #define RAY_OPT_TUNE_MERGE_GRID       8
 #define RAY_OPT_TUNE_FRECHET_SLAB_MB  9
-#define RAY_OPT_TUNE_MERGE_ENTRIES 10     /* 1: the Frechet merge sorts the twelve entries of every record (the round-2 form) instead of its four stencil segments */
+#define RAY_OPT_TUNE_MERGE_ENTRIES    10
 int         ray_ctx_set_option(ray_ctx *ctx, int option, int value);
 /* The host-pointer entry points stage through device buffers the context keeps (grow-only; released by
  * ray_ctx_release_workspaces / ray_ctx_destroy) and copy to / from the caller's arrays.  From pageable memory
