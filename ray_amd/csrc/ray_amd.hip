@@ -2078,6 +2078,9 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
                            drho.as<double>(), f->uoff(), droptol, med->N, lds_rows, num, f->ucols(), f->uvals(), f->rowcnt());
     } else {
         const int max_rows = frechet_rows(cap_max);
+        // four workgroups per CU (40 KB each) when that costs at most an eighth of the rows kept in LDS
+        const int fit4 = (int)((40960 - 64 - (int64_t)max_rows * (kFrSlotsPerCall * 4)) / kSegLdsRowBytes);
+        if (ctx->tune_lds_rows < 0 && fit4 >= lds_rows * 7 / 8) lds_rows = std::min(lds_rows, fit4);
         const size_t emit_lds = seg_emit_lds_bytes(lds_rows, max_rows);
         if (emit_lds > 48 * 1024)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)emit_lds));

@@ -685,7 +685,10 @@ __global__ __launch_bounds__(BT) void k_merge_sort(const int32_t *__restrict__ c
 
 // Theta column of emission e = 12 row + k from the ray's trajectory records (see kTrajDoubles)
 // (`stride`: doubles between consecutive records: kTrajDoubles in the slab, kTrajLdsDoubles in the LDS copy)
-constexpr int kTrajLdsDoubles = kTrajDoubles + 2;      // 144-byte rows: records of different rows on different banks
+// The LDS copy is NOT padded: 128-byte rows put every row's piece on one of two bank groups, but the merge is bound by
+// its instruction count and by occupancy, not by LDS (SQ_LDS_BANK_CONFLICT is 1 % of the SIMD cycles), and the 16 bytes
+// per row are what fits a fourth workgroup on a CU: 5.45 -> 4.97 ms (a 136-byte stride breaks the b128 alignment: 3x slower)
+constexpr int kTrajLdsDoubles = kTrajDoubles;
 __device__ __forceinline__ void theta_of_record(const double2 *__restrict__ rec, unsigned k, double th[4]);
 __device__ __forceinline__ void theta_of_entry(const double *__restrict__ recs, int stride, unsigned e, int N, double th[4], int &node)
 {
