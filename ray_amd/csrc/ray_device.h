@@ -73,6 +73,9 @@ constexpr int kSlotPieces = RAY_SLOT_PIECES;
 constexpr unsigned kSlotBytes = 16u * kSlotPieces;
 constexpr int kPasses = kSlotPieces;                // global_load_lds passes that fill them (P x 1 KiB = 64 slots x 16 P bytes)
 constexpr int kWaveSlotBytes = kPasses * 1024;
+#ifndef RAY_FETCH_PRIO
+#define RAY_FETCH_PRIO 3                            // wave priority from the start of a fetching right-hand side to its DMA issue (0: off)
+#endif
 #ifndef RAY_TAG_ENTRIES
 #define RAY_TAG_ENTRIES 128
 #endif
@@ -304,6 +307,7 @@ __device__ __forceinline__ void fetch_records(const char *rec, const GridAcc &a,
             }
         }
     }
+    if (RAY_FETCH_PRIO) asm volatile("s_setprio 0");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef RAY_ABLATE_NOREAD
     asm volatile("" :: "v"(rank));
@@ -457,6 +461,10 @@ template <int AR, int MODE = kFetch>
 __device__ __forceinline__ void rhs_grid(const GridDev &g, const GridAcc &a, const double X[4], double H[4], OobMax &oob,
                                          unsigned long long lm, RecState &rs)
 {
+    // A wave on its way to a fetch goes first: its memory requests leave early and the waves of a SIMD drift out of step,
+    // so that one computes while another waits (cell indices -> leaders -> DMA issue at priority 3, back to 0 before the
+    // wait; the wait and the read-back at raised priority cost 3 %: profiles/r3).  -1.9 % kernel time.
+    if (RAY_FETCH_PRIO && MODE == kFetch) asm volatile("s_setprio %0" :: "n"(RAY_FETCH_PRIO));
     double dx, dy;                                                   // kFused: set here, in cell units
     int i = cell_of<AR>(X[0], g, oob, a.nb_v, dx);
     int j = cell_of<AR>(X[1], g, oob, a.nb_v, dy);
