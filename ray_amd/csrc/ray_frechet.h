@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_build_hess(const double *__restrict__ r
 struct PointEval {
     int i, j;                 // 0-based cell
     double dx, dy, c, gcX, gcY, tau;
+    double2 hs[6];            // the cell's hess record
 };
 
 // table look-up at X (per-lane loads), H in the chosen flavour          NonObstacle.jl:30-42
@@ -74,6 +75,13 @@ __device__ __forceinline__ void point_eval(const GridDev &g, const double X[4], 
     double2 r[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) r[k] = src[k];
+    {   // the hess record of the same cell, asked for with the first one: both gathers in flight together
+        // (hess exists for I,J <= N-3 only: clamp here, flag in jac_from_point)
+        const int ih = q.i < g.N - 4 ? q.i : g.N - 4, jh = q.j < g.N - 4 ? q.j : g.N - 4;
+        const double2 *hs = reinterpret_cast<const double2 *>(g.hrec) + ((size_t)ih + (size_t)jh * (size_t)(g.N - 1)) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q.hs[k] = hs[k];
+    }
     if (AR == kFused) {
         h_from_record<AR>(X, u, v, r, H, q.c, q.gcX, q.gcY, q.tau);
         q.dx = u * g.h;                                     // physical offsets for the hess look-up and dV
@@ -99,7 +107,7 @@ __device__ __forceinline__ void jac_from_point(const GridDev &g, const double X[
     // hess exists for I,J <= N-3 only: clamp + flag (reference: out-of-bounds read)
     const int ih = q.i < g.N - 4 ? q.i : g.N - 4, jh = q.j < g.N - 4 ? q.j : g.N - 4;
     oob |= (ih != q.i) | (jh != q.j);
-    const double2 *hs = reinterpret_cast<const double2 *>(g.hrec) + ((size_t)ih + (size_t)jh * (size_t)(g.N - 1)) * 6;
+    const double2 *hs = q.hs;
     const double dxdy = q.dx * q.dy;
     const double hXX = bil(q.dx, q.dy, dxdy, hs[0], hs[1]);
     const double hXY = bil(q.dx, q.dy, dxdy, hs[2], hs[3]);
