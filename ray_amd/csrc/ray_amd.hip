@@ -422,6 +422,7 @@ struct TraceArgs {
     double dt;
     int mode;
     double cease_r;       // 1 + 2*(p[2]-p[1])                      NonObstacle.jl:177
+    double cease_s2;      // the largest s = x^2 + y^2 with fl(sqrt(s)) <= cease_r
     int max_steps;
     double *X;
     int64_t ldx;
@@ -502,14 +503,10 @@ __global__ __launch_bounds__(256, (AR == kFused && !PATH) ? RAY_TRACE_WAVES : 1)
             steps = it;
             oob |= oob_hit(a.med.g, o) | !(s == s);
             if (a.mode == RAY_TRACE_SHORTEN_CEASE) {
-                // norm(X[1:2]) > 1 + 2h: the sqrt is only needed inside a thin shell around the
-                // threshold; outside it the squared comparison decides with certainty.
-                const double c2 = a.cease_r * a.cease_r;
-                bool out;
-                if (s > c2 * 1.0000000001) out = true;
-                else if (s < c2 * 0.9999999999) out = false;
-                else out = __builtin_sqrt(s) > a.cease_r;
-                if (out) { t = t + (T - t); st |= kStCeased; }                    // NonObstacle.jl:177-181
+                // norm(X[1:2]) > 1 + 2h  <=>  s > cease_s2, the largest s whose rounded root is still <= 1 + 2h (the host
+                // derives it: the rounded root is monotone in s) -- no square root per step.  (A "thin shell" form that
+                // took the root only near the threshold was if-converted by the compiler into a root at every step.)
+                if (s > a.cease_s2) { t = t + (T - t); st |= kStCeased; }       // NonObstacle.jl:177-181
             }
             if (PATH) put(Xn[0], Xn[1]);                    // res = [res X[1:2]]      Obstacle.jl:266
             active = t < T;
@@ -1464,6 +1461,15 @@ int ray_shoot_to_exit_dev(ray_ctx *ctx, const ray_medium *med, const ray_obstacl
     return shoot_to_exit_impl(ctx, med, ob, prm, m_dev, ld, status_dev, nsteps_dev, nreflect_dev);
 }
 
+// the largest double s with fl(sqrt(s)) <= r (r > 0): `norm(X) > r` on s = x^2 + y^2 without the square root
+static double sqrt_le_threshold(double r)
+{
+    double t = r * r;
+    while (std::sqrt(t) > r) t = std::nextafter(t, 0.0);
+    while (std::sqrt(std::nextafter(t, INFINITY)) <= r) t = std::nextafter(t, INFINITY);
+    return t;
+}
+
 static int copy_cols_h2d(ray_ctx *ctx, double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int c0, int ncol)
 {
     if (ldd == rows && lds == rows) {                  // the columns abut on both sides: one flat copy
@@ -1760,6 +1766,7 @@ static int trace_dev_impl(ray_ctx *ctx, const ray_medium *med, const double *m_d
     a.med = medium_dev(med);
     a.m = m_dev; a.num = num; a.ld = ld; a.dt = dt; a.mode = mode;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
+    a.cease_s2 = sqrt_le_threshold(a.cease_r);
     a.max_steps = 10000000;
     a.X = X_dev; a.ldx = ldx; a.status = status_dev; a.nsteps = nsteps_dev;
     a.step_counter = ctx->d_steps;
@@ -2025,6 +2032,7 @@ static int forward_operator_impl(ray_ctx *ctx, ray_medium *med, const double *m_
     a.med = medium_dev(med);
     a.m = dm.as<double>(); a.num = num; a.ld = num; a.dt = dt; a.max_steps = max_steps;
     a.cease_r = 1 + 2 * (med->p[1] - med->p[0]);
+    a.cease_s2 = sqrt_le_threshold(a.cease_r);
     a.wave_base = dbase.as<int64_t>(); a.wave_cap = dcap.as<int32_t>(); a.perm = dperm.as<int32_t>();
     a.traj = dtraj.as<double>(); a.cells = dcells.as<int32_t>();
     a.X = dX.as<double>(); a.ldx = num; a.rho = drho.as<double>();

@@ -228,6 +228,7 @@ struct FrechetArgs {
     double dt;
     int max_steps;
     double cease_r;
+    double cease_s2;            // the largest x^2 + y^2 whose rounded root is <= cease_r
     const int64_t *wave_base;   // record-row offset of every wave (a wave owns 64 x rows records from 64 * base)
     const int32_t *wave_cap;    // step capacity of every wave (rows = cap + 1 records per ray)
     const int32_t *perm;        // lane l of wave w integrates ray perm[64 w + l] (rays regrouped by step count, longest first)
@@ -420,12 +421,7 @@ __global__ __launch_bounds__(64, 2) void k_frechet(const FrechetArgs a)
             wp = dtl * 0.5;                                                  // :174-175
             const double s = X[0] * X[0] + X[1] * X[1];
             oob |= o | !(s == s);
-            const double c2 = a.cease_r * a.cease_r;
-            bool out;
-            if (s > c2 * 1.0000000001) out = true;
-            else if (s < c2 * 0.9999999999) out = false;
-            else out = __builtin_sqrt(s) > a.cease_r;
-            if (out) { wp = wp + (T - t); t = t + (T - t); st |= kStCeased; }   // :177-181
+            if (s > a.cease_s2) { wp = wp + (T - t); t = t + (T - t); st |= kStCeased; }   // :177-181 (norm > 1 + 2h without the root)
             active = t < T;
             fin = !active;
         }
