@@ -8,14 +8,15 @@
 //                  node in its ray's own contiguous stretch of the trajectory slab -- the three 4-vectors
 //                  P, Q, S that Theta = inv(rho) dV w factors into, the in-cell offsets and the cell -- plus
 //                  the cell alone in a compact [wave][step][lane] array for the sort;
-//   k_merge_sort   one workgroup per ray sorts that ray's (node, emission order) keys -- 12 stencil nodes
-//                  per record, derived from the cell -- in LDS, ranks the distinct nodes and hands over
-//                  4 bytes per entry (rank | head flag | emission index);
-//   k_merge_emit   rebuilds each entry's Theta column from its record (held in LDS), sums every node's
-//                  contributions in emission order (the order of the reference's Phi += Theta), applies the
-//                  final rho (M rows = rho * Phi, :184) and writes the ray's BLOCK ROW: one column index and
-//                  the four values of rows 4 ray .. 4 ray + 3 per distinct node (36 B instead of 48 B of CSR);
-//                  it also counts, per matrix row, the entries that survive droptol.
+//   k_seg_sort     one workgroup per ray sorts the four stencil SEGMENTS of every record -- runs of consecutive nodes,
+//                  derived from the cell -- by first node in LDS, counts the distinct nodes (what the segments own) and
+//                  hands over 2 bytes per segment (its id in sorted order);
+//   k_seg_emit     one distinct node per thread: rebuilds the Theta columns that reach it from their records (held in
+//                  LDS), sums them in sorted order, applies the final rho (M rows = rho * Phi, :184) and writes the
+//                  ray's BLOCK ROW: one column index and the four values of rows 4 ray .. 4 ray + 3 per distinct node
+//                  (36 B instead of 48 B of CSR); it also counts, per matrix row, the entries that survive droptol.
+//   (k_merge_sort / k_merge_emit: the round-2 form of the same two steps, sorting the twelve entries of every record;
+//   kept behind RAY_OPT_TUNE_MERGE_ENTRIES as a cross-check.)
 // The block rows are the device-resident form of M: the loop passes (k_br_*) apply droptol on the fly.
 //   k_csr_emit     converts to CSR (rows ray-major like reshape(M, 4num, N^2), columns sorted) on export only.
 // The reference goes through LAPACK inv / BLAS gemm here, so parity is by tolerance; the X
