@@ -717,10 +717,12 @@ __device__ __forceinline__ void theta_of_record(const double2 *__restrict__ rec,
     const double gam = (kk & 2u) ? -(fx0 * fy1) : fx0 * fy1;
     if (k < 4u) {
         const double2 p0 = rec[0], p1 = rec[1], q0 = rec[2], q1 = rec[3], s0 = rec[4], s1 = rec[5];
-        th[0] = (phi * p0.x + psi * q0.x) + gam * s0.x;
-        th[1] = (phi * p0.y + psi * q0.y) + gam * s0.y;
-        th[2] = (phi * p1.x + psi * q1.x) + gam * s1.x;
-        th[3] = (phi * p1.y + psi * q1.y) + gam * s1.y;
+        // (phi P + psi Q) + gam S, multiply-adds contracted (M is defined up to rounding: the reference forms it through
+        // LAPACK / BLAS products)
+        th[0] = __builtin_fma(gam, s0.x, __builtin_fma(psi, q0.x, phi * p0.x));
+        th[1] = __builtin_fma(gam, s0.y, __builtin_fma(psi, q0.y, phi * p0.y));
+        th[2] = __builtin_fma(gam, s1.x, __builtin_fma(psi, q1.x, phi * p1.x));
+        th[3] = __builtin_fma(gam, s1.y, __builtin_fma(psi, q1.y, phi * p1.y));
     } else {
         const bool xs = k < 8u;
         const double2 c0 = xs ? rec[2] : rec[4], c1 = xs ? rec[3] : rec[5];
@@ -774,7 +776,7 @@ __device__ __forceinline__ void emit_tiles(const uint32_t *__restrict__ rk_g, co
             double o4[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
-                o4[i] = ((R[i * 4] * s[0] + R[i * 4 + 1] * s[1]) + R[i * 4 + 2] * s[2]) + R[i * 4 + 3] * s[3];
+                o4[i] = __builtin_fma(R[i * 4 + 3], s[3], __builtin_fma(R[i * 4 + 2], s[2], __builtin_fma(R[i * 4 + 1], s[1], R[i * 4] * s[0])));
                 kept |= (unsigned)((droptol < 0) || (__builtin_fabs(o4[i]) > droptol)) << i;     // droptol! (:242)
             }
             ucols[u] = (int32_t)node;
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_seg_emit(const uint32_t *__restrict__ s
         double o4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                                                   // rho * Phi (:184)
-            o4[i] = ((R[i * 4] * s4[0] + R[i * 4 + 1] * s4[1]) + R[i * 4 + 2] * s4[2]) + R[i * 4 + 3] * s4[3];
+            o4[i] = __builtin_fma(R[i * 4 + 3], s4[3], __builtin_fma(R[i * 4 + 2], s4[2], __builtin_fma(R[i * 4 + 1], s4[1], R[i * 4] * s4[0])));
             cnt[i] += (droptol < 0) || (__builtin_fabs(o4[i]) > droptol);                    // droptol! (:242)
         }
         const int64_t u = off + x;
