@@ -155,3 +155,25 @@ def test_library_reads_no_environment_variable():
     for f in os.listdir(os.path.join(ROOT, "ray_amd", "csrc")):
         if f.endswith((".hip", ".h")):
             assert "getenv" not in open(os.path.join(ROOT, "ray_amd", "csrc", f)).read(), f
+
+
+def test_stencil_segments_cover_the_twelve_nodes():
+    """ray_frechet.h sorts the FOUR SEGMENTS of a record's stencil instead of its twelve nodes: in node order (i + j N) the
+    stencil (NonObstacle.jl:107-139: the cell's nodes, its x-neighbours, its y-neighbours) is the rows j-1 (i, i+1), j and
+    j+1 (i-1 .. i+2), j+2 (i, i+1).  The header's packed constants (stencil_di / stencil_dj, and the nibble table that maps
+    (segment, x-offset) back to the stencil index) must say exactly that."""
+    import re
+    src = open(os.path.join(ROOT, "ray_amd", "csrc", "ray_frechet.h")).read()
+    di_c = int(re.search(r"stencil_di\(int k\) \{ return \(int\)\(\((0x[0-9a-f]+)u >>", src).group(1), 16)
+    dj_c = int(re.search(r"stencil_dj\(int k\) \{ return \(int\)\(\((0x[0-9a-f]+)u >>", src).group(1), 16)
+    tab = int(re.search(r"\(unsigned\)\((0x[0-9a-f]+)ull >> \(4 \* \(sg \* 4 \+ di \+ 1\)\)\)", src).group(1), 16)
+    di = [((di_c >> (2 * k)) & 3) - 1 for k in range(12)]
+    dj = [((dj_c >> (2 * k)) & 3) - 1 for k in range(12)]
+    assert di == [0, 1, 0, 1, 2, -1, 2, -1, 0, 1, 0, 1] and dj == [0, 0, 1, 1, 0, 0, 1, 1, 2, 2, -1, -1]
+    seen = set()
+    for sg, (lo, hi) in enumerate([(0, 1), (-1, 2), (-1, 2), (0, 1)]):          # rows j - 1 + sg
+        for d in range(lo, hi + 1):
+            k = (tab >> (4 * (sg * 4 + d + 1))) & 15
+            assert (di[k], dj[k]) == (d, sg - 1), (sg, d, k)
+            seen.add(k)
+    assert seen == set(range(12))
