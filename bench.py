@@ -107,6 +107,12 @@ def secondary_timings(ctx, torch, np, ray_amd, rdev, dev, m, status, nsteps, num
     e.update(workload="config 3: analytic SinProd(0.2,2pi,pi) + circle 0.3, 2048x2048 rays, dt=1e-2 (k_shoot<sinprod,circle>)",
              reflections=int(nrf.sum().item()), not_exited=int((status != ray_amd.ST_EXITED).sum().item()))
     out["config3_analytic_circle"] = e
+    # the same workload around the obstacle WITH CAVITIES (the trefoil of ObstacleDemo.jl:23-24,30-31: up to four reflections per ray)
+    e = timed(shoot(ray_amd.SinProd.obstacle_demo(), ray_amd.Trefoil.demo(), ray_amd.TIME_STEPS))
+    e.update(workload="config 3 with the cavity obstacle: analytic SinProd(0.2,2pi,pi) + trefoil(0.4,0.3,0.2), 2048x2048 rays, dt=1e-2 "
+                      "(k_shoot<sinprod,trefoil>)",
+             reflections=int(nrf.sum().item()), not_exited=int((status != ray_amd.ST_EXITED).sum().item()))
+    out["config3_analytic_trefoil"] = e
     # config 1's medium at the same size (what ScatterRelation runs in NonObstacleDemo.jl)
     e = timed(shoot(ray_amd.SinProd.smooth_demo(), None, ray_amd.TIME_SECONDS))
     e.update(workload="analytic SinProd(0.3,1.5pi,1.5pi), 2048x2048 rays, dt=1e-2 (k_shoot<sinprod,none>)",
