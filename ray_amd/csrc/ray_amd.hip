@@ -444,7 +444,7 @@ struct TraceArgs {
 // PATH = 1 also records `res` of NonReflectionPlot (Obstacle.jl:256,266): the start and the position after
 // every step.
 #ifndef RAY_TRACE_WAVES
-#define RAY_TRACE_WAVES 4               // waves per SIMD of the fused trace kernel (114 VGPRs; 5 = 96 VGPRs with 10 spilled was 2 % slower: profiles/r3)
+#define RAY_TRACE_WAVES 5               // waves per SIMD of the fused trace kernel (96 VGPRs, 5 spilled; as k_shoot: 31.7 KB of LDS per workgroup)
 #endif
 template <int AR, int PATH = 0>
 __global__ __launch_bounds__(256, (AR == kFused && !PATH) ? RAY_TRACE_WAVES : 1) void k_trace(const TraceArgs a)
