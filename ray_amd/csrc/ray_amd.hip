@@ -177,7 +177,7 @@ __device__ __forceinline__ void lerp4(double E[4], const double P[4], const doub
 #define RAY_SHOOT_WAVES 5
 #endif
 template <int MED, int OB, int AR, int PATH = 0>
-__global__ __launch_bounds__(256, (MED == kGrid && OB == kObNone && AR == kFused && !PATH) ? RAY_SHOOT_WAVES : (MED == kSinProd && !PATH) ? RAY_ANALYTIC_WAVES : 1) void k_shoot(const ShootArgs a)
+__global__ __launch_bounds__(256, (MED == kGrid && (OB == kObNone || OB == kObCircle) && AR == kFused && !PATH) ? RAY_SHOOT_WAVES : (MED == kSinProd && !PATH) ? RAY_ANALYTIC_WAVES : 1) void k_shoot(const ShootArgs a)
 {
     // Work mapping.  Explicit states: row = global thread id.  Generated boundary grid: a wave is
     // 64 consecutive directions ("chunk") of one source, a workgroup is the same chunk of
